@@ -1,0 +1,207 @@
+/* gsmcal.h -- C ABI of libgsmcal.so: the GSM FCCH+SCH calibration DSP chain of
+ * JiaoXianjun/multi-rtl-sdr-calibration on AMD MI355X (gfx950), hand-written HIP kernels.
+ *
+ * The reference has no FFI layer: the path sits behind MATLAB function calls
+ * (gsm_sync_demod.m:107-124, multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,164).  Each entry point
+ * below replaces one reference function -- the file:line it replaces is cited -- with the same
+ * argument meaning, the same 1-based positions held in doubles, and the same sentinel outputs
+ * (position = -1, r = -1, ppm = inf, pos_info = [-1 -1]).  A MEX gateway (mex/gsmcal_mex.c) or the
+ * ctypes mirror (multi-rtl-sdr-calibration_amd/api.py) binds them; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - complex data: interleaved double[2] (re, im), column-major like MATLAB's interleaved API.
+ *   - host entry points (no suffix) take HOST pointers, copy, run on the GPU, and return after the
+ *     stream has drained.  `_dev` entry points take DEVICE pointers, only enqueue work on the
+ *     context's HIP stream and return; call gsmcal_sync() before reading results.
+ *   - return value: 0 = ok; > 0 = the reference's algorithmic sentinel was produced (outputs hold
+ *     the sentinel values, exactly as the .m file would return them); < 0 = API / HIP failure
+ *     (outputs undefined).  Where MATLAB itself would stop with an index error (SURVEY 8a pitfall
+ *     12) the call returns GSMCAL_E_INDEX instead of reading out of bounds.
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe.
+ *   - there is no CPU fallback: without a usable gfx950 device gsmcal_ctx_create fails.
+ */
+#ifndef GSMCAL_H
+#define GSMCAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsmcal_ctx gsmcal_ctx;
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+enum {
+    GSMCAL_OK = 0,
+    /* > 0: algorithmic sentinels (the reference returns normally with sentinel outputs) */
+    GSMCAL_S_NO_FCCH = 1,         /* FCCH_coarse_position.m:27-30   position = snr = -1          */
+    GSMCAL_S_FEW_HITS = 2,        /* FCCH_fine_correction.m:12-15 / SCH_corr_rate_correction.m:11 */
+    GSMCAL_S_FINE_FEW = 3,        /* FCCH_fine_correction.m:69: fewer than 5 fine positions       */
+    GSMCAL_S_FINE_SPACING = 4,    /* FCCH_fine_correction.m:95-102  FCCH_pos = -1                 */
+    GSMCAL_S_FINE_FEW_BURSTS = 5, /* FCCH_fine_correction.m:135-142 <5 bursts left, carrier skipped*/
+    GSMCAL_S_FINE_LOW_SNR = 6,    /* FCCH_fine_correction.m:192-196 FCCH_pos = -1                 */
+    GSMCAL_S_SCH_EDGE = 7,        /* SCH_corr_rate_correction.m:59-63 pos_info = [-1 -1]          */
+    GSMCAL_S_SCH_FEW = 8,         /* SCH_corr_rate_correction.m:84: fewer than 5 SCH positions    */
+    GSMCAL_S_SCH_SPACING = 9,     /* SCH_corr_rate_correction.m:106-112                           */
+    GSMCAL_S_POST_NO_POS = 10,    /* carrier_correct_post_SCH.m:10-13                             */
+    GSMCAL_S_POST_FEW_BCCH = 11,  /* carrier_correct_post_SCH.m:15-19                             */
+    GSMCAL_S_ALL_INF = 12,        /* total_ppm_calculation.m:7-11                                 */
+    /* < 0: failures */
+    GSMCAL_E_ARG = -1,
+    GSMCAL_E_HIP = -2,
+    GSMCAL_E_NO_DEVICE = -3,
+    GSMCAL_E_CAPACITY = -4,       /* an output buffer capacity argument is too small             */
+    GSMCAL_E_INDEX = -5,          /* MATLAB would raise "index exceeds matrix dimensions"         */
+    GSMCAL_E_UNSUPPORTED = -6
+};
+
+#define GSMCAL_MAX_HITS 24          /* capacity for FCCH/SCH hits per stream (ceil(len/1562.5)) */
+#define GSMCAL_MAX_POS_ROWS (6 * GSMCAL_MAX_HITS)
+#define GSMCAL_TABLE_COLS 10
+
+/* columns of one row of the calibration table (doubles; this row is what ranks all-gather) */
+enum {
+    GSMCAL_T_SAMPLING_PPM_FCCH = 0, /* FCCH_fine_correction sampling_ppm      (gsm_sync_demod.m:118) */
+    GSMCAL_T_SAMPLING_PPM_SCH = 1,  /* SCH_corr_rate_correction sampling_ppm  (:119)                 */
+    GSMCAL_T_CARRIER_PPM_FCCH = 2,  /* FCCH_fine_correction carrier_ppm       (:118)                 */
+    GSMCAL_T_CARRIER_PPM_POST = 3,  /* carrier_correct_post_SCH carrier_ppm   (:120)                 */
+    GSMCAL_T_TOTAL_SAMPLING_PPM = 4,/* total_ppm_calculation                  (:123)                 */
+    GSMCAL_T_TOTAL_CARRIER_PPM = 5, /* total_ppm_calculation                  (:124)                 */
+    GSMCAL_T_N_FCCH = 6,            /* length(FCCH_pos) after FCCH_fine_correction (1 if sentinel)   */
+    GSMCAL_T_N_POS_ROWS = 7,        /* rows of pos_info (1 if sentinel)                              */
+    GSMCAL_T_FIRST_FCCH_POS = 8,    /* pos_info(1,1) or -1                                           */
+    GSMCAL_T_STATUS = 9             /* first non-zero status code met along the chain               */
+};
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* Creates a context on GPU `device_id` with its own non-blocking HIP stream. */
+int gsmcal_ctx_create(int device_id, gsmcal_ctx** out);
+/* Same, but enqueue on an existing hipStream_t (passed as void*; 0 = the default stream). */
+int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** out);
+void gsmcal_ctx_destroy(gsmcal_ctx* ctx);
+int gsmcal_sync(gsmcal_ctx* ctx);
+const char* gsmcal_last_error(gsmcal_ctx* ctx);
+const char* gsmcal_version(void);
+/* device memory helpers so a host program needs no HIP headers */
+int gsmcal_dev_alloc(gsmcal_ctx* ctx, size_t bytes, void** dptr);
+int gsmcal_dev_free(gsmcal_ctx* ctx, void* dptr);
+int gsmcal_memcpy_h2d(gsmcal_ctx* ctx, void* dst, const void* src, size_t bytes);
+int gsmcal_memcpy_d2h(gsmcal_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Per-kernel timing with HIP events on the context's stream.  enable=1 brackets every kernel launch
+ * with events (serialises nothing, adds two event records per launch).  Stats accumulate until reset. */
+int gsmcal_profile_enable(gsmcal_ctx* ctx, int enable);
+int gsmcal_profile_reset(gsmcal_ctx* ctx);
+/* Returns the number of distinct kernels seen; fills up to `cap` entries (name pointers stay valid
+ * for the life of the library). total_ms[i] is the summed duration, launches[i] the launch count. */
+int gsmcal_profile_get(gsmcal_ctx* ctx, int cap, const char** names, double* total_ms, long* launches);
+
+/* ---- the nine reference functions, MATLAB signatures (host pointers, synchronous) -------------- */
+
+/* b = raw2iq(a)                                                     raw2iq.m:5-8
+ * a: 2N x D doubles holding byte values (column-major); b: N x D complex. */
+int gsmcal_raw2iq(gsmcal_ctx* ctx, const double* a, long rows_2n, int d, double* b);
+/* same with the bytes as they come off the wire (fread(...,'uint8') before MATLAB widens them) */
+int gsmcal_raw2iq_u8(gsmcal_ctx* ctx, const uint8_t* a, long rows_2n, int d, double* b);
+
+/* r = chn_filter_8x_4x(s)                                           chn_filter_8x_4x.m:5-15
+ * s: N x D complex; r: ceil(N/2) x D complex.  `num`/`ntaps`: the numerator the reference loads
+ * from gsm_chn_filter_8x.mat (:9-10); pass NULL/0 to use the built-in 60 taps of
+ * gsm_chn_filter_8x.fda. */
+int gsmcal_chn_filter_8x_4x(gsmcal_ctx* ctx, const double* s, long n, int d,
+                            const double* num, int ntaps, double* r);
+/* r = filter(coef, 1, s) column-wise (gsm_sync_demod.m:110, multi_rtl_sdr_gsm_FCCH_scanner.m:133);
+ * keep every `decim`-th row starting with row 1 (decim = 1: all rows; the drivers' r(1:64:end,i)). */
+int gsmcal_filter(gsmcal_ctx* ctx, const double* coef, int ntaps, const double* s, long n, int d,
+                  int decim, double* r);
+
+/* [hit_flag,hit_idx,hit_avg_snr,hit_snr] = move_fft_snr_runtime_avg(s,mv_len,fft_len,th)
+ *                                                                    move_fft_snr_runtime_avg.m:5-50 */
+int gsmcal_move_fft_snr_runtime_avg(gsmcal_ctx* ctx, const double* s, long len, int mv_len, int fft_len,
+                                    double th, int* hit_flag, double* hit_idx, double* hit_avg_snr,
+                                    double* hit_snr);
+/* [hit_flag,hit_idx,hit_snr] = specific_fft_snr_fix_avg(s,target_set,fft_len,th,avg_snr)
+ *                                                                    specific_fft_snr_fix_avg.m:5-34 */
+int gsmcal_specific_fft_snr_fix_avg(gsmcal_ctx* ctx, const double* s, long len, const double target_set[2],
+                                    int fft_len, double th, double avg_snr, int* hit_flag,
+                                    double* hit_idx, double* hit_snr);
+/* [position,snr] = FCCH_coarse_position(s,decimation_ratio)         FCCH_coarse_position.m:5-94
+ * position/snr: capacity `cap` doubles; *count = number of hits (sentinel: *count = 1, both -1). */
+int gsmcal_FCCH_coarse_position(gsmcal_ctx* ctx, const double* s, long len, int decimation_ratio,
+                                double* position, double* snr, int cap, int* count);
+
+/* [FCCH_pos,r,sampling_ppm,carrier_ppm] = FCCH_fine_correction(s,base_position,ov,carrier_freq)
+ *                                                                    FCCH_fine_correction.m:5-197
+ * r: capacity cap_r complex samples; *len_r = samples written (sentinel r = -1: *len_r = -1 and
+ * nothing written).  r may be NULL (cap_r = 0) when only positions/ppm are wanted. */
+int gsmcal_FCCH_fine_correction(gsmcal_ctx* ctx, const double* s, long len, const double* base_position,
+                                int num_base, int oversampling_ratio, double carrier_freq,
+                                double* fcch_pos, int cap_pos, int* num_pos,
+                                double* r, long cap_r, long* len_r,
+                                double* sampling_ppm, double* carrier_ppm);
+
+/* [pos_info,r,sampling_ppm] = SCH_corr_rate_correction(s,FCCH_pos,sch_training_sequence,ov)
+ *                                                                    SCH_corr_rate_correction.m:5-181
+ * pos_info: cap_rows x 2 doubles, column-major with leading dimension cap_rows; *num_rows rows valid
+ * (sentinel: *num_rows = 1, row = [-1 -1]). */
+int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* ctx, const double* s, long len, const double* fcch_pos,
+                                    int num_fcch, const double* sch_training_sequence, int len_ts,
+                                    int oversampling_ratio, double* pos_info, int cap_rows, int* num_rows,
+                                    double* r, long cap_r, long* len_r, double* sampling_ppm);
+
+/* [r,carrier_ppm] = carrier_correct_post_SCH(s,pos_info,ov,carrier_freq)
+ *                                                                    carrier_correct_post_SCH.m:5-83
+ * pos_info: rows x 2 column-major, leading dimension `ld`. */
+int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* ctx, const double* s, long len, const double* pos_info,
+                                    int rows, int ld, int oversampling_ratio, double carrier_freq,
+                                    double* r, long cap_r, long* len_r, double* carrier_ppm);
+
+/* ppm_out = total_ppm_calculation(ppm_in)                           total_ppm_calculation.m:5-21
+ * (pure host arithmetic; no context needed) */
+int gsmcal_total_ppm_calculation(const double* ppm_in, int n, double* ppm_out);
+
+/* ---- batched hot path (what the drivers' loops become) ----------------------------------------- */
+
+/* Front end of both drivers for D captures at once: raw2iq + filter(coef,1,.) + r(1:decim:end)
+ * (gsm_sync_demod.m:107,110,117; multi_rtl_sdr_gsm_FCCH_scanner.m:132-135).
+ * raw: D x 2N bytes (capture-major: capture d starts at raw + d*2N). out: D x ceil(N/decim) complex. */
+int gsmcal_frontend_batch(gsmcal_ctx* ctx, const uint8_t* raw, int d, long n, const double* coef,
+                          int ntaps, int decim, double* out);
+int gsmcal_frontend_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, long n, const double* coef,
+                              int ntaps, int decim, double* d_out);
+
+/* Scanner detect loop for D captures (multi_rtl_sdr_gsm_FCCH_scanner.m:132-135 front end,
+ * :164 FCCH_coarse_position, :168-185 acceptance).  Outputs per capture: snr, num_hit (as the
+ * driver's arrays), optional positions/snrs [D][GSMCAL_MAX_HITS] and counts [D] (NULL to skip). */
+int gsmcal_fcch_scan_batch(gsmcal_ctx* ctx, const uint8_t* raw, int d, long n, const double* coef,
+                           int ntaps, double* snr, double* num_hit, double* positions,
+                           double* pos_snr, int* counts);
+int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, long n, const double* coef,
+                               int ntaps, double* d_snr_numhit /* [D][2] */, double* d_positions,
+                               double* d_pos_snr, int* d_counts);
+
+/* Per-dongle body of gsm_sync_demod.m:107-124 for D streams at once, from raw bytes to the
+ * calibration table.  carrier_freq: [D].  table: [D][GSMCAL_TABLE_COLS].
+ * Optional outputs (NULL to skip): pos_info [D][2][GSMCAL_MAX_POS_ROWS] (per stream column-major,
+ * ld = GSMCAL_MAX_POS_ROWS); r_correct [D][N] complex + r_len [D] (the corrected stream the
+ * reference hands to SCH_demod; r_len = -1 where the reference returns r = -1). */
+int gsmcal_calibrate_batch(gsmcal_ctx* ctx, const uint8_t* raw, int d, long n, const double* coef,
+                           int ntaps, const double* sch_training_sequence, int len_ts,
+                           const double* carrier_freq, double* table, double* pos_info,
+                           double* r_correct, long* r_len);
+int gsmcal_calibrate_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, long n, const double* coef,
+                               int ntaps, const double* sch_training_sequence, int len_ts,
+                               const double* carrier_freq, double* d_table, double* d_pos_info,
+                               double* d_r_correct, long* d_r_len);
+
+/* Debug/parity taps into the last calibrate/scan batch: copies per-stream intermediates to host.
+ * coarse_pos/coarse_snr/fine_first/fcch_pos/sch_first: [D][GSMCAL_MAX_HITS]; counts: [D][5]
+ * (n_coarse, n_fine_first, n_fcch, n_sch_first, n_pos_rows).  Any pointer may be NULL. */
+int gsmcal_last_batch_details(gsmcal_ctx* ctx, int d, double* coarse_pos, double* coarse_snr,
+                              double* fine_first, double* fcch_pos, double* sch_first, int* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSMCAL_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libgsmcal.so (include/gsmcal.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_long_p = C.POINTER(C.c_long)
+c_u8_p = C.POINTER(C.c_uint8)
+
+MAX_HITS = 24
+MAX_POS_ROWS = 6 * MAX_HITS
+TABLE_COLS = 10
+
+# every extern "C" symbol include/gsmcal.h declares: (restype, argtypes)
+SIGNATURES = {
+    "gsmcal_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_ctx_create_on_stream": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gsmcal_ctx_destroy": (None, [C.c_void_p]),
+    "gsmcal_sync": (C.c_int, [C.c_void_p]),
+    "gsmcal_last_error": (C.c_char_p, [C.c_void_p]),
+    "gsmcal_version": (C.c_char_p, []),
+    "gsmcal_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gsmcal_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gsmcal_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gsmcal_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gsmcal_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gsmcal_profile_reset": (C.c_int, [C.c_void_p]),
+    "gsmcal_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), c_double_p, c_long_p]),
+    "gsmcal_raw2iq": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p]),
+    "gsmcal_raw2iq_u8": (C.c_int, [C.c_void_p, c_u8_p, C.c_long, C.c_int, c_double_p]),
+    "gsmcal_chn_filter_8x_4x": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p, C.c_int, c_double_p]),
+    "gsmcal_filter": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p, C.c_long, C.c_int, C.c_int, c_double_p]),
+    "gsmcal_move_fft_snr_runtime_avg": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, C.c_int, C.c_double,
+                                                  c_int_p, c_double_p, c_double_p, c_double_p]),
+    "gsmcal_specific_fft_snr_fix_avg": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, C.c_double,
+                                                  C.c_double, c_int_p, c_double_p, c_double_p]),
+    "gsmcal_FCCH_coarse_position": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p, c_double_p,
+                                              C.c_int, c_int_p]),
+    "gsmcal_FCCH_fine_correction": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, C.c_int,
+                                              C.c_double, c_double_p, C.c_int, c_int_p, c_double_p, C.c_long,
+                                              c_long_p, c_double_p, c_double_p]),
+    "gsmcal_SCH_corr_rate_correction": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, c_double_p,
+                                                  C.c_int, C.c_int, c_double_p, C.c_int, c_int_p, c_double_p,
+                                                  C.c_long, c_long_p, c_double_p]),
+    "gsmcal_carrier_correct_post_SCH": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, C.c_int,
+                                                  C.c_int, C.c_double, c_double_p, C.c_long, c_long_p, c_double_p]),
+    "gsmcal_total_ppm_calculation": (C.c_int, [c_double_p, C.c_int, c_double_p]),
+    "gsmcal_frontend_batch": (C.c_int, [C.c_void_p, c_u8_p, C.c_int, C.c_long, c_double_p, C.c_int, C.c_int,
+                                        c_double_p]),
+    "gsmcal_frontend_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, c_double_p, C.c_int, C.c_int,
+                                            C.c_void_p]),
+    "gsmcal_fcch_scan_batch": (C.c_int, [C.c_void_p, c_u8_p, C.c_int, C.c_long, c_double_p, C.c_int, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, c_int_p]),
+    "gsmcal_fcch_scan_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, c_double_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsmcal_calibrate_batch": (C.c_int, [C.c_void_p, c_u8_p, C.c_int, C.c_long, c_double_p, C.c_int, c_double_p,
+                                         C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_long_p]),
+    "gsmcal_calibrate_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, c_double_p, C.c_int,
+                                             c_double_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "gsmcal_last_batch_details": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            c_double_p, c_int_p]),
+}
+
+
+class GsmcalError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load libgsmcal.so and attach prototypes.  Raises GsmcalError if it is absent and cannot be built:
+    there is no CPU fallback in this package."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise GsmcalError(f"{path} is missing (build it with __graft_entry__.build()); no CPU fallback exists")
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise GsmcalError(f"libgsmcal.so is missing and could not be built: {e}") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

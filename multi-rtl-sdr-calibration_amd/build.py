@@ -1,0 +1,44 @@
+"""Build libgsmcal.so (HIP, gfx950) in-tree with hipcc.  No torch, no cmake: one translation unit."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "gsmcal.hip")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libgsmcal.so")
+
+
+def _deps():
+    d = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    d.append(os.path.join(HERE, "..", "include", "gsmcal.h"))
+    return d
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/gsmcal.hip -> lib/libgsmcal.so for gfx950.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libgsmcal.so cannot be built (there is no CPU fallback)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=HERE)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

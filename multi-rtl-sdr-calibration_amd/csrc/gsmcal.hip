@@ -1,0 +1,920 @@
+// gsmcal.hip -- host side of libgsmcal.so: context, workspace, launch sequences, C ABI (include/gsmcal.h).
+//
+// The calibration chain is enqueued as a fixed sequence of kernels on one HIP stream; all
+// data-dependent control lives in StreamState on the device (see state.h).  The same building
+// blocks serve the per-function MATLAB-signature entry points (level 0 = a complex array handed in)
+// and the batched hot path (level 0 = FIR of the raw bytes, evaluated lazily window by window).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gsmcal.h"
+#include "builtin_taps.h"
+#include "kernels_detect.h"
+#include "kernels_estim.h"
+#include "kernels_frontend.h"
+#include "state.h"
+
+#define GSMCAL_VERSION "gsmcal-mi355x 0.1 (gfx950)"
+#define TILE 1024
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int name_id;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct gsmcal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // workspace
+    DevBuf state, coef, ts, cf, dec, win, peaks, edge, table, snrhit, arr_in, arr_out, posinfo, rlen, misc;
+    std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
+    int last_S = 0;
+    // profiling
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<long> prof_n;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                \
+            return GSMCAL_E_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+#define RET_IF(x)             \
+    do {                      \
+        int r__ = (x);        \
+        if (r__ < 0) return r__; \
+    } while (0)
+
+int ensure(gsmcal_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+int prof_id(gsmcal_ctx* c, const char* name) {
+    for (size_t i = 0; i < c->prof_names.size(); ++i)
+        if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name);
+    c->prof_ms.push_back(0.0);
+    c->prof_n.push_back(0);
+    return (int)c->prof_names.size() - 1;
+}
+
+hipEvent_t get_event(gsmcal_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int prof_flush(gsmcal_ctx* c) {
+    if (c->prof_pending.empty()) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            c->prof_ms[r.name_id] += ms;
+            c->prof_n[r.name_id] += 1;
+        }
+        c->ev_pool.push_back(r.e0);
+        c->ev_pool.push_back(r.e1);
+    }
+    c->prof_pending.clear();
+    return 0;
+}
+
+struct ProfScope {
+    gsmcal_ctx* c;
+    ProfRec r;
+    bool on;
+    ProfScope(gsmcal_ctx* ctx, const char* name) : c(ctx), on(ctx->prof) {
+        if (on) {
+            r.name_id = prof_id(c, name);
+            r.e0 = get_event(c);
+            r.e1 = get_event(c);
+            (void)hipEventRecord(r.e0, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(r.e1, c->stream);
+            c->prof_pending.push_back(r);
+            if (c->prof_pending.size() > 60000) (void)prof_flush(c);
+        }
+    }
+};
+
+#define LAUNCH(c, kern, grid, block, shmem, ...)                                  \
+    do {                                                                          \
+        ProfScope ps__(c, #kern);                                                 \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (c)->stream, __VA_ARGS__);   \
+    } while (0)
+
+#define CHECK_LAUNCH(c) HIPCHK(c, hipGetLastError())
+
+int upload_cached(gsmcal_ctx* c, DevBuf& b, std::vector<double>& host, const double* src, size_t n) {
+    if (host.size() == n && b.p && memcmp(host.data(), src, n * sizeof(double)) == 0) return 0;
+    RET_IF(ensure(c, b, n * sizeof(double)));
+    host.assign(src, src + n);
+    HIPCHK(c, hipMemcpyAsync(b.p, host.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+__global__ void k_init_state(StreamState* sts, int S, long n0) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    // zero everything, then the few non-zero defaults (sentinels of the reference functions)
+    unsigned long long* w = (unsigned long long*)st;
+    for (size_t i = 0; i < sizeof(StreamState) / 8; ++i) w[i] = 0ull;
+    st->n0 = n0;
+    st->hit_avg_snr = INFINITY;
+    st->sampling_ppm1 = st->carrier_ppm1 = st->sampling_ppm2 = st->carrier_ppm2 = INFINITY;
+    st->fcch_is_sentinel = 1;
+}
+
+struct Geom {  // burst geometry for an oversampling ratio
+    int ov, nfft, fine_wlen, fine_nshift, NB, sch_nshift;
+    explicit Geom(int ov_) : ov(ov_) {
+        nfft = 148 * ov;
+        fine_nshift = 128 * ov + 1;          // FCCH_fine_correction.m:40-46: 2*max_offset*ov + 1
+        fine_wlen = fine_nshift - 1 + nfft;
+        NB = (nfft + 255) / 256;
+        sch_nshift = 16 * ov - 5 * ov + 1;   // SCH_corr_rate_correction.m:45-48
+    }
+};
+
+struct Source {
+    int kind;
+    const uint8_t* raw; long raw_stride;
+    const cplx* arr; long arr_stride;
+    const double* coef; int ntaps;
+};
+
+size_t gather_lds(int len, int level, int kind, int ntaps) {
+    size_t bufn = (size_t)len + 8;
+    size_t b = 2 * bufn * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * 8;
+    if (kind == SRC_RAW) b += (bufn + ntaps + 8) * 2;
+    (void)level;
+    return (b + 15) & ~(size_t)15;
+}
+
+int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, bool tiles, int nwin_grid,
+                  cplx* dst, long dst_stream_stride, long dst_win_stride) {
+    GatherArgs a;
+    a.src_kind = src.kind; a.level = level; a.len = len; a.tiles = tiles ? 1 : 0; a.ntaps = src.ntaps; a.pad = 0;
+    a.raw = src.raw; a.raw_stride = src.raw_stride; a.arr = src.arr; a.arr_stride = src.arr_stride;
+    a.coef = src.coef; a.dst = dst; a.dst_stream_stride = dst_stream_stride; a.dst_win_stride = dst_win_stride;
+    const size_t lds = gather_lds(len, level, src.kind, src.ntaps);
+    LAUNCH(c, k_gather, dim3(nwin_grid, S), dim3(256), lds, (const StreamState*)c->state.p, a);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ---- FCCH_fine_correction body (input at level lvl; creates levels lvl+1 (lerp), lvl+2 (mix)) ----
+int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H) {
+    StreamState* st = (StreamState*)c->state.p;
+    const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
+    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
+    RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    cplx* win = (cplx*)c->win.p;
+    PeakOut* peaks = (PeakOut*)c->peaks.p;
+    const int tb = 64, gb = (S + tb - 1) / tb;
+    LAUNCH(c, k_fine_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
+    RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
+    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.fine_wlen * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.fine_wlen, g.nfft, 0, peaks, H, g.NB);
+    LAUNCH(c, k_fine_decide, dim3(gb), dim3(tb), 0, st, S, (const PeakOut*)peaks, H, g.NB, g.ov, lvl);
+    // bursts of the resampled (not yet derotated) stream: level lvl+1
+    RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
+    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, 1, peaks, H, g.NB);
+    const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
+    LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
+           (const PeakOut*)peaks, H, g.NB, g.ov, 1);
+    LAUNCH(c, k_carrier_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ---- SCH_corr_rate_correction body (input at level lvl; creates level lvl+1) ----
+int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, int len_ts) {
+    StreamState* st = (StreamState*)c->state.p;
+    const int wl = g.sch_nshift - 1 + len_ts;
+    const long wstride = g.fine_wlen > wl ? g.fine_wlen : wl, sstride = (long)H * wstride;
+    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
+    RET_IF(ensure(c, c->edge, (size_t)S * sizeof(int)));
+    cplx* win = (cplx*)c->win.p;
+    const int tb = 64, gb = (S + tb - 1) / tb;
+    LAUNCH(c, k_sch_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, len_ts, lvl, (int*)c->edge.p);
+    RET_IF(launch_gather(c, S, src, lvl, wl, false, H, win, sstride, wstride));
+    const size_t lds = (size_t)(wl + len_ts) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+    LAUNCH(c, k_sch_corr, dim3(H, S), dim3(128), lds, st, (const cplx*)win, sstride, wstride,
+           (const cplx*)c->ts.p, len_ts, g.sch_nshift, (int*)c->edge.p);
+    LAUNCH(c, k_sch_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl, (const int*)c->edge.p);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ---- carrier_correct_post_SCH body (input at level lvl; creates level lvl+1 (mix)) ----
+int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H) {
+    StreamState* st = (StreamState*)c->state.p;
+    const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
+    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
+    RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    cplx* win = (cplx*)c->win.p;
+    PeakOut* peaks = (PeakOut*)c->peaks.p;
+    const int tb = 64, gb = (S + tb - 1) / tb;
+    LAUNCH(c, k_post_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
+    RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
+    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, 1, peaks, H, g.NB);
+    const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
+    LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
+           (const PeakOut*)peaks, H, g.NB, g.ov, 0);
+    LAUNCH(c, k_post_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+int init_states(gsmcal_ctx* c, int S, long n0) {
+    RET_IF(ensure(c, c->state, (size_t)S * sizeof(StreamState)));
+    LAUNCH(c, k_init_state, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S, n0);
+    CHECK_LAUNCH(c);
+    c->last_S = S;
+    return 0;
+}
+
+int dc_means(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n) {
+    int blocks = (int)((2 * n / 16 + 256 * 8 - 1) / (256 * 8));
+    if (blocks < 1) blocks = 1;
+    int cap = 4096 / (S > 0 ? S : 1);
+    if (cap < 1) cap = 1;
+    if (blocks > cap) blocks = cap;
+    LAUNCH(c, k_dc_sum, dim3(blocks, S), dim3(256), 0, d_raw, 2 * n, (StreamState*)c->state.p);
+    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
+                  cplx* d_out, long out_stride) {
+    const long nd = (n + decim - 1) / decim;
+    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (size_t)(256 * decim + ntaps + 8) * 2;
+    if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
+    LAUNCH(c, k_fir_decim_raw, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
+           (const StreamState*)c->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+int hits_capacity(long len_dec, int dec_ratio) {
+    // FCCH_coarse_position.m:38 max_num_fcch = ceil(len/(10*num_sym_per_frame/decimation_ratio))
+    int h = (int)ceil((double)len_dec / (12500.0 / (double)dec_ratio));
+    if (h < 1) h = 1;
+    return h;
+}
+
+int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio) {
+    CoarseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
+    const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
+    const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
+    const size_t lds = (size_t)fft_len * sizeof(cplx) + (size_t)(n_first + 64) * sizeof(double);
+    if (lds > 64 * 1024) return GSMCAL_E_UNSUPPORTED;
+    LAUNCH(c, k_coarse, dim3(S), dim3(256), lds, (StreamState*)c->state.p, a);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+int fetch_states(gsmcal_ctx* c, int S, std::vector<StreamState>& out) {
+    out.resize(S);
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->state.p, (size_t)S * sizeof(StreamState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int push_states(gsmcal_ctx* c, const std::vector<StreamState>& in) {
+    RET_IF(ensure(c, c->state, in.size() * sizeof(StreamState)));
+    HIPCHK(c, hipMemcpyAsync(c->state.p, in.data(), in.size() * sizeof(StreamState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void host_init_state(StreamState& st, long n0) {
+    memset(&st, 0, sizeof(st));
+    st.n0 = n0;
+    st.hit_avg_snr = INFINITY;
+    st.sampling_ppm1 = st.carrier_ppm1 = st.sampling_ppm2 = st.carrier_ppm2 = INFINITY;
+    st.fcch_is_sentinel = 1;
+}
+
+// materialise level `level` of stream 0 (API mode, array source) into host buffer r
+int materialise_to_host(gsmcal_ctx* c, const Source& src, int level, long n_out, double* r) {
+    RET_IF(ensure(c, c->arr_out, (size_t)n_out * sizeof(cplx)));
+    const int tiles = (int)((n_out + TILE - 1) / TILE);
+    RET_IF(launch_gather(c, 1, src, level, TILE, true, tiles, (cplx*)c->arr_out.p, n_out, 0));
+    HIPCHK(c, hipMemcpyAsync(r, c->arr_out.p, (size_t)n_out * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
+    RET_IF(ensure(c, c->arr_in, n_cplx * sizeof(cplx)));
+    HIPCHK(c, hipMemcpyAsync(c->arr_in.p, s, n_cplx * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int positive_status(const StreamState& st, int stage) {
+    if (st.status < 0) return st.status;
+    return st.stage_status[stage];
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* gsmcal_version(void) { return GSMCAL_VERSION; }
+
+int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** out) {
+    if (!out) return GSMCAL_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GSMCAL_E_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return GSMCAL_E_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return GSMCAL_E_HIP;
+    // kernels whose dynamic LDS may exceed the 64 KiB default
+    (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    gsmcal_ctx* c = new gsmcal_ctx();
+    c->device = device_id;
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    *out = c;
+    return 0;
+}
+
+int gsmcal_ctx_create(int device_id, gsmcal_ctx** out) {
+    int r = gsmcal_ctx_create_on_stream(device_id, nullptr, out);
+    if (r != 0) return r;
+    gsmcal_ctx* c = *out;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        *out = nullptr;
+        return GSMCAL_E_HIP;
+    }
+    c->own_stream = true;
+    return 0;
+}
+
+void gsmcal_ctx_destroy(gsmcal_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->state, &c->coef, &c->ts, &c->cf, &c->dec, &c->win, &c->peaks, &c->edge, &c->table,
+                      &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen, &c->misc};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gsmcal_sync(gsmcal_ctx* c) {
+    if (!c) return GSMCAL_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+const char* gsmcal_last_error(gsmcal_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gsmcal_dev_alloc(gsmcal_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dptr, bytes));
+    return 0;
+}
+int gsmcal_dev_free(gsmcal_ctx* c, void* dptr) {
+    if (!c) return GSMCAL_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(dptr));
+    return 0;
+}
+int gsmcal_memcpy_h2d(gsmcal_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return GSMCAL_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gsmcal_memcpy_d2h(gsmcal_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return GSMCAL_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsmcal_profile_enable(gsmcal_ctx* c, int enable) {
+    if (!c) return GSMCAL_E_ARG;
+    RET_IF(prof_flush(c));
+    c->prof = enable != 0;
+    return 0;
+}
+int gsmcal_profile_reset(gsmcal_ctx* c) {
+    if (!c) return GSMCAL_E_ARG;
+    RET_IF(prof_flush(c));
+    for (auto& v : c->prof_ms) v = 0.0;
+    for (auto& v : c->prof_n) v = 0;
+    return 0;
+}
+int gsmcal_profile_get(gsmcal_ctx* c, int cap, const char** names, double* total_ms, long* launches) {
+    if (!c) return GSMCAL_E_ARG;
+    RET_IF(prof_flush(c));
+    const int n = (int)c->prof_names.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = c->prof_names[i].c_str();
+        if (total_ms) total_ms[i] = c->prof_ms[i];
+        if (launches) launches[i] = c->prof_n[i];
+    }
+    return n;
+}
+
+// ---- a1 raw2iq -----------------------------------------------------------------------------------
+int gsmcal_raw2iq_u8(gsmcal_ctx* c, const uint8_t* a, long rows_2n, int d, double* b) {
+    if (!c || !a || !b || rows_2n < 2 || (rows_2n & 1) || d < 1) return GSMCAL_E_ARG;
+    const long n = rows_2n / 2;
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(ensure(c, c->misc, (size_t)rows_2n * d));
+    RET_IF(ensure(c, c->arr_out, (size_t)n * d * sizeof(cplx)));
+    HIPCHK(c, hipMemcpyAsync(c->misc.p, a, (size_t)rows_2n * d, hipMemcpyHostToDevice, c->stream));
+    RET_IF(init_states(c, d, n));
+    RET_IF(dc_means(c, (const uint8_t*)c->misc.p, d, n));
+    int blocks = (int)((n + 256 * 4 - 1) / (256 * 4));
+    if (blocks > 2048) blocks = 2048;
+    LAUNCH(c, k_raw2iq, dim3(blocks, d), dim3(256), 0, (const uint8_t*)c->misc.p, rows_2n,
+           (const StreamState*)c->state.p, (cplx*)c->arr_out.p, n);
+    CHECK_LAUNCH(c);
+    HIPCHK(c, hipMemcpyAsync(b, c->arr_out.p, (size_t)n * d * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsmcal_raw2iq(gsmcal_ctx* c, const double* a, long rows_2n, int d, double* b) {
+    if (!c || !a || !b || rows_2n < 2 || (rows_2n & 1) || d < 1) return GSMCAL_E_ARG;
+    // the doubles hold byte values (fread(...,'uint8'), gsm_sync_demod.m:96): narrow them back
+    const size_t tot = (size_t)rows_2n * d;
+    std::vector<uint8_t> u(tot);
+    for (size_t i = 0; i < tot; ++i) {
+        const double v = a[i];
+        if (!(v >= 0.0 && v <= 255.0) || v != floor(v)) {
+            c->err = "raw2iq: input is not byte-valued (only uint8-valued captures are supported)";
+            return GSMCAL_E_UNSUPPORTED;
+        }
+        u[i] = (uint8_t)v;
+    }
+    return gsmcal_raw2iq_u8(c, u.data(), rows_2n, d, b);
+}
+
+// ---- a2 filters ----------------------------------------------------------------------------------
+int gsmcal_filter(gsmcal_ctx* c, const double* coef, int ntaps, const double* s, long n, int d, int decim, double* r) {
+    if (!c || !coef || !s || !r || ntaps < 1 || n < 1 || d < 1 || decim < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const long nd = (n + decim - 1) / decim;
+    RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
+    RET_IF(upload_array(c, s, (size_t)n * d));
+    RET_IF(ensure(c, c->arr_out, (size_t)nd * d * sizeof(cplx)));
+    LAUNCH(c, k_fir_arr, dim3((unsigned)((nd + 255) / 256), d), dim3(256), 0, (const cplx*)c->arr_in.p, n, n,
+           (const double*)c->coef.p, ntaps, decim, nd, (cplx*)c->arr_out.p, nd);
+    CHECK_LAUNCH(c);
+    HIPCHK(c, hipMemcpyAsync(r, c->arr_out.p, (size_t)nd * d * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsmcal_chn_filter_8x_4x(gsmcal_ctx* c, const double* s, long n, int d, const double* num, int ntaps, double* r) {
+    if (!num || ntaps <= 0) { num = GSM_CHN_FILTER_8X_NUM; ntaps = 60; }
+    return gsmcal_filter(c, num, ntaps, s, n, d, 2, r);   // chn_filter_8x_4x.m:13,15
+}
+
+// ---- a3..a5 coarse detector -----------------------------------------------------------------------
+static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, StreamState* out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(upload_array(c, s, (size_t)len));
+    RET_IF(init_states(c, 1, len));
+    a.s = (const cplx*)c->arr_in.p; a.s_stride = len; a.len = len;
+    int fft_len = a.fft_len;
+    long nwin_cap = len;
+    if (a.mode == 0) {
+        fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
+        nwin_cap = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
+    }
+    if (fft_len < 2 || fft_len > 64) return GSMCAL_E_UNSUPPORTED;
+    const size_t lds = (size_t)fft_len * sizeof(cplx) + (size_t)(nwin_cap + 64) * sizeof(double);
+    if (lds > 160 * 1024 - 256) return GSMCAL_E_UNSUPPORTED;
+    LAUNCH(c, k_coarse, dim3(1), dim3(256), lds, (StreamState*)c->state.p, a);
+    CHECK_LAUNCH(c);
+    std::vector<StreamState> v;
+    RET_IF(fetch_states(c, 1, v));
+    *out = v[0];
+    return 0;
+}
+
+int gsmcal_move_fft_snr_runtime_avg(gsmcal_ctx* c, const double* s, long len, int mv_len, int fft_len, double th,
+                                    int* hit_flag, double* hit_idx, double* hit_avg_snr, double* hit_snr) {
+    if (!c || !s || len < 1 || mv_len < 1 || fft_len < 2) return GSMCAL_E_ARG;
+    CoarseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = 1; a.mv_len = mv_len; a.fft_len = fft_len; a.th = th; a.decimation_ratio = 8;
+    StreamState st;
+    RET_IF(coarse_api(c, s, len, a, &st));
+    if (st.status < 0) return st.status;
+    if (hit_flag) *hit_flag = st.coarse_hit_flag;
+    if (hit_idx) *hit_idx = st.coarse_hit_flag ? st.mv_hit_idx : -1.0;
+    if (hit_avg_snr) *hit_avg_snr = st.coarse_hit_flag ? st.hit_avg_snr : INFINITY;
+    if (hit_snr) *hit_snr = st.coarse_hit_flag ? st.mv_hit_snr : INFINITY;
+    return 0;
+}
+
+int gsmcal_specific_fft_snr_fix_avg(gsmcal_ctx* c, const double* s, long len, const double target_set[2], int fft_len,
+                                    double th, double avg_snr, int* hit_flag, double* hit_idx, double* hit_snr) {
+    if (!c || !s || !target_set || len < 1 || fft_len < 2) return GSMCAL_E_ARG;
+    CoarseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = 2; a.fft_len = fft_len; a.th = th; a.avg_snr = avg_snr; a.decimation_ratio = 8; a.mv_len = 1;
+    a.t_lo = (long)target_set[0]; a.t_hi = (long)target_set[1];
+    StreamState st;
+    RET_IF(coarse_api(c, s, len, a, &st));
+    if (st.status < 0) return st.status;
+    if (hit_flag) *hit_flag = st.coarse_hit_flag;
+    if (hit_idx) *hit_idx = st.coarse_hit_flag ? st.mv_hit_idx : -1.0;
+    if (hit_snr) *hit_snr = st.coarse_hit_flag ? st.mv_hit_snr : INFINITY;
+    return 0;
+}
+
+int gsmcal_FCCH_coarse_position(gsmcal_ctx* c, const double* s, long len, int decimation_ratio, double* position,
+                                double* snr, int cap, int* count) {
+    if (!c || !s || !position || !snr || !count || len < 1 || decimation_ratio < 1 || cap < 1) return GSMCAL_E_ARG;
+    if (hits_capacity(len, decimation_ratio) > MAXH) return GSMCAL_E_CAPACITY;
+    CoarseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = 0; a.decimation_ratio = decimation_ratio;
+    StreamState st;
+    RET_IF(coarse_api(c, s, len, a, &st));
+    if (st.status < 0) return st.status;
+    if (st.n_coarse == 0) {
+        position[0] = -1.0; snr[0] = -1.0; *count = 1;
+        return GSMCAL_S_NO_FCCH;
+    }
+    if (st.n_coarse > cap) return GSMCAL_E_CAPACITY;
+    for (int i = 0; i < st.n_coarse; ++i) { position[i] = st.coarse_pos[i]; snr[i] = st.coarse_snr[i]; }
+    *count = st.n_coarse;
+    return 0;
+}
+
+// ---- a6 FCCH_fine_correction ------------------------------------------------------------------------
+int gsmcal_FCCH_fine_correction(gsmcal_ctx* c, const double* s, long len, const double* base_position, int num_base,
+                                int ov, double carrier_freq, double* fcch_pos, int cap_pos, int* num_pos, double* r,
+                                long cap_r, long* len_r, double* sampling_ppm, double* carrier_ppm) {
+    if (!c || !s || !base_position || !fcch_pos || !num_pos || len < 1 || num_base < 0 || ov < 1 || cap_pos < 1)
+        return GSMCAL_E_ARG;
+    if (num_base > MAXH) return GSMCAL_E_CAPACITY;
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom g(ov);
+    RET_IF(upload_array(c, s, (size_t)len));
+    RET_IF(upload_cached(c, c->cf, c->h_cf, &carrier_freq, 1));
+    std::vector<StreamState> v(1);
+    host_init_state(v[0], len);
+    v[0].n_coarse = num_base;
+    for (int i = 0; i < num_base; ++i) v[0].coarse_pos[i] = base_position[i];
+    RET_IF(push_states(c, v));
+    c->last_S = 1;
+    Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
+    const int H = num_base > 0 ? num_base : 1;
+    RET_IF(run_fine(c, 1, src, 0, g, H));
+    RET_IF(fetch_states(c, 1, v));
+    const StreamState& st = v[0];
+    if (st.status < 0) return st.status;
+    if (sampling_ppm) *sampling_ppm = st.sampling_ppm1;
+    if (carrier_ppm) *carrier_ppm = st.carrier_ppm1;
+    if (st.fcch_is_sentinel) {
+        fcch_pos[0] = -1.0;
+        *num_pos = 1;
+    } else {
+        if (st.n_fcch > cap_pos) return GSMCAL_E_CAPACITY;
+        for (int i = 0; i < st.n_fcch; ++i) fcch_pos[i] = st.fcch_pos[i];
+        *num_pos = st.n_fcch;
+    }
+    long lr = -1;
+    int level = 0;
+    if (st.r1_kind == 1) { lr = len; level = 0; }
+    else if (st.r1_kind == 2) { lr = st.op[1].n; level = 1; }
+    else if (st.r1_kind == 3) { lr = st.op[2].n; level = 2; }
+    if (len_r) *len_r = lr;
+    if (r && lr > 0) {
+        if (lr > cap_r) return GSMCAL_E_CAPACITY;
+        if (level == 0) memcpy(r, s, (size_t)lr * sizeof(cplx));
+        else RET_IF(materialise_to_host(c, src, level, lr, r));
+    }
+    return positive_status(st, 0);
+}
+
+// ---- a7 SCH_corr_rate_correction ----------------------------------------------------------------------
+int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, const double* fcch_pos, int num_fcch,
+                                    const double* sch_ts, int len_ts, int ov, double* pos_info, int cap_rows,
+                                    int* num_rows, double* r, long cap_r, long* len_r, double* sampling_ppm) {
+    if (!c || !fcch_pos || !sch_ts || !pos_info || !num_rows || num_fcch < 0 || len_ts < 1 || ov < 1 || cap_rows < 1)
+        return GSMCAL_E_ARG;
+    if (num_fcch > MAXH) return GSMCAL_E_CAPACITY;
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom g(ov);
+    const bool have_s = s != nullptr && len >= 1;   // r = -1 from a failed fine stage arrives as s = NULL
+    if (have_s) RET_IF(upload_array(c, s, (size_t)len));
+    RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
+    std::vector<StreamState> v(1);
+    host_init_state(v[0], have_s ? len : 0);
+    const bool sentinel_in = (num_fcch == 1 && fcch_pos[0] == -1.0);
+    v[0].fcch_is_sentinel = sentinel_in ? 1 : 0;
+    v[0].n_fcch = sentinel_in ? 0 : num_fcch;
+    for (int i = 0; i < num_fcch; ++i) v[0].fcch_pos[i] = fcch_pos[i];
+    if (!have_s && !(sentinel_in || num_fcch < 5)) return GSMCAL_E_ARG;
+    RET_IF(push_states(c, v));
+    c->last_S = 1;
+    Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
+    const int H = num_fcch > 0 ? num_fcch : 1;
+    RET_IF(run_sch(c, 1, src, 0, g, H, len_ts));
+    RET_IF(fetch_states(c, 1, v));
+    const StreamState& st = v[0];
+    if (st.status < 0) return st.status;
+    if (sampling_ppm) *sampling_ppm = st.sampling_ppm2;
+    if (st.n_rows == 0) {
+        pos_info[0] = -1.0;
+        pos_info[cap_rows] = -1.0;
+        *num_rows = 1;
+    } else {
+        if (st.n_rows > cap_rows) return GSMCAL_E_CAPACITY;
+        for (int i = 0; i < st.n_rows; ++i) {
+            pos_info[i] = st.pos_info[i];
+            pos_info[cap_rows + i] = st.pos_info[MAXROWS + i];
+        }
+        *num_rows = st.n_rows;
+    }
+    long lr = -1;
+    int level = 0;
+    if (st.r2_kind == 1) { lr = len; level = 0; }
+    else if (st.r2_kind == 2) { lr = st.op[1].n; level = st.op[1].type == OP_COPY ? 0 : 1; }
+    if (len_r) *len_r = lr;
+    if (r && lr > 0) {
+        if (lr > cap_r) return GSMCAL_E_CAPACITY;
+        if (level == 0) memcpy(r, s, (size_t)lr * sizeof(cplx));
+        else RET_IF(materialise_to_host(c, src, level, lr, r));
+    }
+    return positive_status(st, 1);
+}
+
+// ---- a8 carrier_correct_post_SCH -------------------------------------------------------------------------
+int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, const double* pos_info, int rows, int ld,
+                                    int ov, double carrier_freq, double* r, long cap_r, long* len_r, double* carrier_ppm) {
+    if (!c || !pos_info || rows < 1 || ld < rows || ov < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom g(ov);
+    bool all_m1 = true;                       // `if pos_info == -1` is true only if every element is -1
+    for (int i = 0; i < rows; ++i) all_m1 = all_m1 && pos_info[i] == -1.0 && pos_info[ld + i] == -1.0;
+    if (!all_m1 && rows > MAXROWS) return GSMCAL_E_CAPACITY;
+    const bool have_s = s != nullptr && len >= 1;
+    if (have_s) RET_IF(upload_array(c, s, (size_t)len));
+    RET_IF(upload_cached(c, c->cf, c->h_cf, &carrier_freq, 1));
+    std::vector<StreamState> v(1);
+    host_init_state(v[0], have_s ? len : 0);
+    int nfcch = 0;
+    if (!all_m1) {
+        v[0].n_rows = rows;
+        for (int i = 0; i < rows; ++i) {
+            v[0].pos_info[i] = pos_info[i];
+            v[0].pos_info[MAXROWS + i] = pos_info[ld + i];
+            nfcch += pos_info[ld + i] == 0.0;
+        }
+        if (!have_s) return GSMCAL_E_ARG;
+    }
+    if (nfcch > MAXH) return GSMCAL_E_CAPACITY;
+    RET_IF(push_states(c, v));
+    c->last_S = 1;
+    Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
+    RET_IF(run_post(c, 1, src, 0, g, nfcch > 0 ? nfcch : 1));
+    RET_IF(fetch_states(c, 1, v));
+    const StreamState& st = v[0];
+    if (st.status < 0) return st.status;
+    if (carrier_ppm) *carrier_ppm = st.carrier_ppm2;
+    long lr = st.r3_kind == 3 ? st.op[1].n : -1;
+    if (len_r) *len_r = lr;
+    if (r && lr > 0) {
+        if (lr > cap_r) return GSMCAL_E_CAPACITY;
+        RET_IF(materialise_to_host(c, src, 1, lr, r));
+    }
+    return positive_status(st, 2);
+}
+
+// ---- a9 total_ppm_calculation ---------------------------------------------------------------------------
+int gsmcal_total_ppm_calculation(const double* ppm_in, int n, double* ppm_out) {
+    if (!ppm_in || !ppm_out || n < 1) return GSMCAL_E_ARG;
+    bool all_inf = true;
+    for (int i = 0; i < n; ++i) all_inf = all_inf && ppm_in[i] == INFINITY;
+    if (all_inf) { *ppm_out = INFINITY; return GSMCAL_S_ALL_INF; }   // :7-11
+    double p = 1.0;
+    for (int i = 0; i < n; ++i) p = p * (1.0 + ppm_in[i] * 1e-6);     // :14-18
+    *ppm_out = (p - 1.0) * 1e6;                                        // :20-21
+    return 0;
+}
+
+// ---- batched hot path ---------------------------------------------------------------------------------------
+int gsmcal_frontend_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
+                              int decim, double* d_out) {
+    if (!c || !d_raw || !coef || !d_out || d < 1 || n < 1 || ntaps < 1 || decim < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
+    RET_IF(init_states(c, d, n));
+    RET_IF(dc_means(c, d_raw, d, n));
+    const long nd = (n + decim - 1) / decim;
+    return fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)d_out, nd);
+}
+
+int gsmcal_frontend_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, const double* coef, int ntaps, int decim,
+                          double* out) {
+    if (!c || !raw || !out || d < 1 || n < 1 || decim < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const long nd = (n + decim - 1) / decim;
+    RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
+    RET_IF(ensure(c, c->arr_out, (size_t)nd * d * sizeof(cplx)));
+    HIPCHK(c, hipMemcpyAsync(c->misc.p, raw, (size_t)2 * n * d, hipMemcpyHostToDevice, c->stream));
+    RET_IF(gsmcal_frontend_batch_dev(c, (const uint8_t*)c->misc.p, d, n, coef, ntaps, decim, (double*)c->arr_out.p));
+    HIPCHK(c, hipMemcpyAsync(out, c->arr_out.p, (size_t)nd * d * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
+                               double* d_snr_numhit, double* d_positions, double* d_pos_snr, int* d_counts) {
+    if (!c || !d_raw || !coef || !d_snr_numhit || d < 1 || n < 1 || ntaps < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // ..FCCH_scanner.m:43-45
+    const long nd = (n + decim - 1) / decim;
+    if (hits_capacity(nd, dec_ratio) > MAXH) return GSMCAL_E_CAPACITY;
+    RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
+    RET_IF(ensure(c, c->dec, (size_t)d * nd * sizeof(cplx)));
+    RET_IF(init_states(c, d, n));
+    RET_IF(dc_means(c, d_raw, d, n));
+    RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));
+    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio));
+    LAUNCH(c, k_scan_accept, dim3((d + 63) / 64), dim3(64), 0, (const StreamState*)c->state.p, d, d_snr_numhit,
+           d_positions, d_pos_snr, d_counts);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
+int gsmcal_fcch_scan_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, const double* coef, int ntaps, double* snr,
+                           double* num_hit, double* positions, double* pos_snr, int* counts) {
+    if (!c || !raw || !snr || !num_hit || d < 1 || n < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
+    RET_IF(ensure(c, c->snrhit, (size_t)d * (2 + 2 * MAXH) * sizeof(double) + (size_t)d * sizeof(int)));
+    HIPCHK(c, hipMemcpyAsync(c->misc.p, raw, (size_t)2 * n * d, hipMemcpyHostToDevice, c->stream));
+    double* d_sn = (double*)c->snrhit.p;
+    double* d_pos = d_sn + (size_t)2 * d;
+    double* d_ps = d_pos + (size_t)d * MAXH;
+    int* d_cnt = (int*)(d_ps + (size_t)d * MAXH);
+    RET_IF(gsmcal_fcch_scan_batch_dev(c, (const uint8_t*)c->misc.p, d, n, coef, ntaps, d_sn, d_pos, d_ps, d_cnt));
+    std::vector<double> sn((size_t)2 * d);
+    HIPCHK(c, hipMemcpyAsync(sn.data(), d_sn, sn.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (positions) HIPCHK(c, hipMemcpyAsync(positions, d_pos, (size_t)d * MAXH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pos_snr) HIPCHK(c, hipMemcpyAsync(pos_snr, d_ps, (size_t)d * MAXH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIPCHK(c, hipMemcpyAsync(counts, d_cnt, (size_t)d * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < d; ++i) { snr[i] = sn[2 * i]; num_hit[i] = sn[2 * i + 1]; }
+    return 0;
+}
+
+int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
+                               const double* sch_ts, int len_ts, const double* carrier_freq, double* d_table,
+                               double* d_pos_info, double* d_r_correct, long* d_r_len) {
+    if (!c || !d_raw || !coef || !sch_ts || !carrier_freq || !d_table || d < 1 || n < 1 || ntaps < 1 || len_ts < 1)
+        return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // gsm_sync_demod.m:17-19
+    const Geom g(ov);
+    const long nd = (n + decim - 1) / decim;
+    int H = hits_capacity(nd, dec_ratio) + 1;
+    if (H > MAXH) return GSMCAL_E_CAPACITY;
+    RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
+    RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
+    RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));
+    RET_IF(ensure(c, c->dec, (size_t)d * nd * sizeof(cplx)));
+    RET_IF(init_states(c, d, n));
+    RET_IF(dc_means(c, d_raw, d, n));                                                  // raw2iq.m:8
+    RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));  // :107,110,117
+    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio));                    // :117
+    Source src{SRC_RAW, d_raw, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
+    RET_IF(run_fine(c, d, src, 0, g, H));                                              // :118
+    RET_IF(run_sch(c, d, src, 2, g, H, len_ts));                                       // :119
+    RET_IF(run_post(c, d, src, 3, g, H));                                              // :120
+    LAUNCH(c, k_totals, dim3((d + 63) / 64), dim3(64), 0, (const StreamState*)c->state.p, d, d_table, d_pos_info,
+           d_r_len);                                                                   // :123-124
+    CHECK_LAUNCH(c);
+    if (d_r_correct) {
+        const int tiles = (int)((n + TILE - 1) / TILE);
+        RET_IF(launch_gather(c, d, src, 4, TILE, true, tiles, (cplx*)d_r_correct, n, 0));
+    }
+    return 0;
+}
+
+int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, const double* coef, int ntaps,
+                           const double* sch_ts, int len_ts, const double* carrier_freq, double* table,
+                           double* pos_info, double* r_correct, long* r_len) {
+    if (!c || !raw || !table || d < 1 || n < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
+    RET_IF(ensure(c, c->table, (size_t)d * GSMCAL_TABLE_COLS * sizeof(double)));
+    RET_IF(ensure(c, c->posinfo, (size_t)d * 2 * MAXROWS * sizeof(double)));
+    RET_IF(ensure(c, c->rlen, (size_t)d * sizeof(long)));
+    if (r_correct) RET_IF(ensure(c, c->arr_out, (size_t)d * n * sizeof(cplx)));
+    HIPCHK(c, hipMemcpyAsync(c->misc.p, raw, (size_t)2 * n * d, hipMemcpyHostToDevice, c->stream));
+    RET_IF(gsmcal_calibrate_batch_dev(c, (const uint8_t*)c->misc.p, d, n, coef, ntaps, sch_ts, len_ts, carrier_freq,
+                                      (double*)c->table.p, (double*)c->posinfo.p,
+                                      r_correct ? (double*)c->arr_out.p : nullptr, (long*)c->rlen.p));
+    HIPCHK(c, hipMemcpyAsync(table, c->table.p, (size_t)d * GSMCAL_TABLE_COLS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pos_info)
+        HIPCHK(c, hipMemcpyAsync(pos_info, c->posinfo.p, (size_t)d * 2 * MAXROWS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (r_len) HIPCHK(c, hipMemcpyAsync(r_len, c->rlen.p, (size_t)d * sizeof(long), hipMemcpyDeviceToHost, c->stream));
+    if (r_correct)
+        HIPCHK(c, hipMemcpyAsync(r_correct, c->arr_out.p, (size_t)d * n * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* coarse_snr, double* fine_first,
+                              double* fcch_pos, double* sch_first, int* counts) {
+    if (!c || d < 1 || d > c->last_S) return GSMCAL_E_ARG;
+    std::vector<StreamState> v;
+    RET_IF(fetch_states(c, d, v));
+    for (int s = 0; s < d; ++s) {
+        const StreamState& st = v[s];
+        for (int i = 0; i < MAXH; ++i) {
+            if (coarse_pos) coarse_pos[(size_t)s * MAXH + i] = i < st.n_coarse ? st.coarse_pos[i] : 0.0;
+            if (coarse_snr) coarse_snr[(size_t)s * MAXH + i] = i < st.n_coarse ? st.coarse_snr[i] : 0.0;
+            if (fine_first) fine_first[(size_t)s * MAXH + i] = i < st.n_fine ? st.fine_first[i] : 0.0;
+            if (fcch_pos) fcch_pos[(size_t)s * MAXH + i] = i < st.n_fcch ? st.fcch_pos[i] : 0.0;
+            if (sch_first) sch_first[(size_t)s * MAXH + i] = i < st.n_sch_first ? st.sch_first[i] : 0.0;
+        }
+        if (counts) {
+            counts[5 * s + 0] = st.n_coarse;
+            counts[5 * s + 1] = st.n_fine;
+            counts[5 * s + 2] = st.fcch_is_sentinel ? -1 : st.n_fcch;
+            counts[5 * s + 3] = st.n_sch_first;
+            counts[5 * s + 4] = st.n_rows;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,519 @@
+// kernels_estim.h -- estimators on gathered windows and the per-stream decision kernels.
+//
+//   k_tone        tone-frequency estimator of FCCH_fine_correction.m:148-155 (+ SNR gate :185-189)
+//                 and carrier_correct_post_SCH.m:63-72, one workgroup per FCCH burst
+//   k_sch_corr    SCH_corr_rate_correction.m:50-55: |sch_ts' * window|^2 for the 89 offsets, argmax
+//   k_*_setup / k_*_decide   the integer / ppm logic of the reference functions, one thread per
+//                 stream, writing the next stage's window list into StreamState
+#pragma once
+#include "state.h"
+#include "kernels_frontend.h"
+
+#define GSM_SYMBOL_RATE ((1625.0 / 6.0) * 1e3)
+#define TWO_PI_D (2.0 * 3.14159265358979323846)
+#define PI_D 3.14159265358979323846
+
+// merge the NB partial peaks of one window: larger p wins, equal p -> smaller tie key
+__device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
+    PeakOut b = p[0];
+    for (int i = 1; i < NB; ++i)
+        if (p[i].p > b.p || (p[i].p == b.p && p[i].tie < b.tie)) b = p[i];
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tone: grid (H, S), block 256.  win: bursts of nfft samples.  peaks: spectrum argmax partials.
+// Writes st->fo_burst[w] and (do_gate) st->snr_burst[w].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, const cplx* __restrict__ win,
+                                              long win_stream_stride, long win_stride, int nfft,
+                                              const PeakOut* __restrict__ peaks, int H, int NB,
+                                              int ov, int do_gate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cplx* xs = (cplx*)smem;            // nfft derotated samples
+    cplx* tw = xs + nfft;              // nfft twiddles exp(-2 pi i m / nfft) (gate only)
+    double* P = (double*)(tw + nfft);  // nfft bin powers (only the gate's bins are filled)
+    __shared__ double red[8];
+    __shared__ double sh_phase;
+    const int s = blockIdx.y, w = blockIdx.x;
+    StreamState* st = sts + s;
+    if (w >= st->n_win) return;
+    const int tid = threadIdx.x;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    const PeakOut pk = merge_peaks(peaks + ((size_t)s * H + w) * NB, NB);
+    const int max_idx = pk.tie + 1;                                    // 1-based index after fftshift
+    const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
+    // :151  int_phase_rotate = 2.*pi.*(max_idx - ((fft_len/2)+1))./fft_len
+    const double ipr = (TWO_PI_D * (double)(max_idx - (nfft / 2 + 1))) / (double)nfft;
+    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)
+    for (int n = tid; n < nfft; n += 256) {
+        double sn, cs;
+        sincos((double)n * ipr, &sn, &cs);
+        xs[n] = cmul(x[n], make_double2(cs, -sn));
+    }
+    __syncthreads();
+    // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) )
+    double sr = 0.0, si = 0.0;
+    for (int n = tid; n < nfft - 1; n += 256) {
+        const cplx a = xs[n + 1], b = xs[n];
+        const double ma = hypot(a.x, a.y), mb = hypot(b.x, b.y);
+        const cplx ua = ma > 0.0 ? make_double2(a.x / ma, a.y / ma) : make_double2(1.0, 0.0);
+        const cplx ub = mb > 0.0 ? make_double2(b.x / mb, b.y / mb) : make_double2(1.0, 0.0);
+        const double den = ub.x * ub.x + ub.y * ub.y;
+        sr += (ua.x * ub.x + ua.y * ub.y) / den;
+        si += (ua.y * ub.x - ua.x * ub.y) / den;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        si += __shfl_down(si, off, 64);
+    }
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sr; red[2 * (tid >> 6) + 1] = si; }
+    __syncthreads();
+    if (tid == 0) {
+        double tr = 0.0, ti = 0.0;
+        for (int i = 0; i < 4; ++i) { tr += red[2 * i]; ti += red[2 * i + 1]; }
+        const double cnt = (double)(nfft - 1);
+        const double phase = atan2(ti / cnt, tr / cnt);
+        sh_phase = phase;
+        st->fo_burst[w] = sampling_rate * (ipr + phase) / TWO_PI_D;   // :155
+    }
+    if (!do_gate) return;
+    __syncthreads();
+    // ---- SNR gate, FCCH_fine_correction.m:185-189 ----
+    const double phase = sh_phase;
+    for (int n = tid; n < nfft; n += 256) {
+        double sn, cs;
+        sincos((double)n * phase, &sn, &cs);
+        const cplx v = xs[n];                       // each n is owned by exactly one thread
+        xs[n] = cmul(v, make_double2(cs, -sn));
+        sincospi(-2.0 * (double)n / (double)nfft, &sn, &cs);
+        tw[n] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
+    // bins needed: [0, hnl) and [nfft-hnl, nfft)
+    const int nb = 2 * hnl;
+    for (int b = tid; b < nb; b += 256) {
+        const int k = b < hnl ? b : nfft - nb + b;
+        double ar = 0.0, ai = 0.0;
+        int idx = 0;
+        for (int n = 0; n < nfft; ++n) {
+            const cplx v = xs[n], t = tw[idx];
+            ar += v.x * t.x - v.y * t.y;
+            ai += v.x * t.y + v.y * t.x;
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        const double m = hypot(ar, ai);
+        P[k] = m * m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // signal: fd([1:3, end-1:end]); noise: fd([4:hnl, end-hnl+1:end-2])   (1-based)
+        double sig = 0.0, noi = 0.0;
+        for (int k = 0; k < 3; ++k) sig += P[k];
+        for (int k = nfft - 2; k < nfft; ++k) sig += P[k];
+        for (int k = 3; k < hnl; ++k) noi += P[k];
+        for (int k = nfft - hnl; k < nfft - 2; ++k) noi += P[k];
+        st->snr_burst[w] = 10.0 * log10(sig / noi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sch_corr: grid (H, S), block 128.  window length nshift-1+len_ts; ts = sch_training_sequence.
+// Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; edge peaks flagged in *edge_flags.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_sch_corr(StreamState* __restrict__ sts, const cplx* __restrict__ win,
+                                                  long win_stream_stride, long win_stride,
+                                                  const cplx* __restrict__ ts, int len_ts, int nshift,
+                                                  int* __restrict__ edge_flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cplx* xs = (cplx*)smem;                 // window
+    cplx* tc = xs + (nshift - 1 + len_ts);  // conj(ts)
+    double* cv = (double*)(tc + len_ts);    // nshift correlation powers
+    const int s = blockIdx.y, w = blockIdx.x;
+    StreamState* st = sts + s;
+    if (w >= st->n_win) return;
+    const int tid = threadIdx.x;
+    const int wl = nshift - 1 + len_ts;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    for (int i = tid; i < wl; i += 128) xs[i] = x[i];
+    for (int i = tid; i < len_ts; i += 128) tc[i] = make_double2(ts[i].x, -ts[i].y);
+    __syncthreads();
+    for (int o = tid; o < nshift; o += 128) {
+        double ar = 0.0, ai = 0.0;
+        for (int n = 0; n < len_ts; ++n) {
+            const cplx c = tc[n], v = xs[o + n];
+            ar += c.x * v.x - c.y * v.y;
+            ai += c.x * v.y + c.y * v.x;
+        }
+        const double m = hypot(ar, ai);
+        cv[o] = m * m;                      // :53 abs(...).^2
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int mi = 0;
+        double mx = cv[0];
+        for (int o = 1; o < nshift; ++o)
+            if (cv[o] > mx) { mx = cv[o]; mi = o; }
+        st->sch_first[w] = (double)(st->win_start[w] + 1 + mi);   // sp + max_idx - 1
+        if (mi == 0 || mi == nshift - 1) atomicOr(&edge_flags[s], 1);   // :59
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decision kernels: one thread per stream
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fine_sentinel(StreamState* st) {
+    st->n_fcch = 0; st->fcch_is_sentinel = 1;
+    st->sampling_ppm1 = INFINITY; st->carrier_ppm1 = INFINITY;
+    st->r1_kind = 0; st->n_win = 0; st->n_fine = 0;
+}
+
+// FCCH_fine_correction.m:8-46 -- window list for the fine search (level `lvl`)
+__global__ void k_fine_setup(StreamState* sts, int S, int ov, int lvl) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    fine_sentinel(st);
+    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+    if (st->status < 0) return;
+    if (st->n_coarse < 5) { set_status(st, 0, GSMCAL_S_FEW_HITS); return; }   // :12
+    const long len_s_ov = level_len(st, lvl);
+    const long len_s = len_s_ov / ov;                                          // :28
+    const int max_offset = 64, len_cw = 148;
+    int cnt = 0;
+    for (int i = 0; i < st->n_coarse && i < MAXH; ++i) {
+        const long position = (long)st->coarse_pos[i];
+        if (position + max_offset > len_s - len_cw + 1) break;                 // :35
+        const long sp = (position - max_offset - 1) * ov + 1;                  // :40,43
+        if (sp < 1) { set_status(st, 0, GSMCAL_E_INDEX); st->n_win = 0; return; }
+        st->win_start[cnt++] = sp - 1;
+    }
+    st->n_win = cnt;
+}
+
+// FCCH_fine_correction.m:52-137 -- positions, sampling error, new grid, burst windows at level lvl+1
+__global__ void k_fine_decide(StreamState* sts, int S, const PeakOut* peaks, int H, int NB, int ov, int lvl) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    if (st->status < 0 || st->stage_status[0] != 0) { st->n_win = 0; return; }
+    const int last_idx = st->n_win;
+    for (int w = 0; w < last_idx; ++w) {
+        const PeakOut pk = merge_peaks(peaks + ((size_t)s * H + w) * NB, NB);
+        st->fine_first[w] = (double)(st->win_start[w] + 1 + pk.tie);          // sp + max_idx - 1
+    }
+    st->n_fine = last_idx;
+    st->n_win = 0;
+    const int fft_len = 148 * ov;
+    if (last_idx < 5) {                                                        // :69 not taken
+        st->fcch_is_sentinel = 0;
+        st->n_fcch = last_idx;
+        for (int w = 0; w < last_idx; ++w) st->fcch_pos[w] = st->fine_first[w];
+        set_status(st, 0, GSMCAL_S_FINE_FEW);
+        return;
+    }
+    const double d_ov = 10.0 * 1250.0 * (double)ov, d1_ov = 11.0 * 1250.0 * (double)ov;   // :80-81
+    const double max_ppm = 4000.0;
+    const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
+    int na = 0, nb = 0;
+    double expected = 0.0;
+    unsigned a_mask = 0, b_mask = 0;
+    for (int i = 0; i < last_idx - 1; ++i) {
+        const double diff = st->fine_first[i + 1] - st->fine_first[i];
+        if (fabs(diff - d_ov) < max_th) { ++na; a_mask |= 1u << i; }
+        if (fabs(diff - d1_ov) < max_th1) { ++nb; b_mask |= 1u << i; }
+    }
+    if (na + nb != last_idx - 1) {                                             // :95-102
+        st->r1_kind = 1;  // r = s was already assigned (:72)
+        set_status(st, 0, GSMCAL_S_FINE_SPACING);
+        return;
+    }
+    expected = (double)na * d_ov + (double)nb * d1_ov;                         // :111
+    const double actual = st->fine_first[last_idx - 1] - st->fine_first[0];
+    const double e = (actual - expected) / expected;                           // :113
+    st->sampling_ppm1 = e * 1e6;
+    const long len_r = level_len(st, lvl);
+    const long max_len = e >= 0.0 ? (long)floor((double)len_r / (1.0 + e)) : len_r;   // :118-122
+    st->op[lvl + 1].type = OP_LERP;
+    st->op[lvl + 1].param = 1.0 + e;
+    st->op[lvl + 1].n = max_len;
+    st->r1_kind = 2;
+    // :127-133 regenerated grid
+    const double first = round((st->fine_first[0] - 1.0) / (1.0 + e)) + 1.0;
+    double acc = 1.0;
+    int n = last_idx;
+    st->fcch_pos[0] = acc + first - 1.0;
+    for (int i = 0; i < last_idx - 1; ++i) {
+        double step = 0.0;
+        if (a_mask & (1u << i)) step = d_ov;
+        if (b_mask & (1u << i)) step = d1_ov;
+        acc += step;
+        st->fcch_pos[i + 1] = acc + first - 1.0;
+    }
+    if (st->fcch_pos[n - 1] + (double)fft_len - 1.0 > (double)max_len) --n;  // :135
+    st->n_fcch = n;
+    st->fcch_is_sentinel = 0;
+    if (n >= 5) {                                                              // :142
+        for (int i = 0; i < n; ++i) {
+            const long sp = (long)st->fcch_pos[i];
+            if (sp < 1 || sp + fft_len - 1 > max_len) { set_status(st, 0, GSMCAL_E_INDEX); return; }
+            st->win_start[i] = sp - 1;
+        }
+        st->n_win = n;
+    } else {
+        set_status(st, 0, GSMCAL_S_FINE_FEW_BURSTS);
+    }
+}
+
+// mean(fo), carrier ppm and the derotation op; shared by fine (:158-165) and post-SCH (:75-83)
+__device__ __forceinline__ double carrier_from_bursts(StreamState* st, int nb, int ov, double carrier_freq,
+                                                      int op_level, long n, double* ppm) {
+    const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
+    const double target_freq = GSM_SYMBOL_RATE / 4.0;
+    double fo = 0.0;
+    for (int i = 0; i < nb; ++i) fo += st->fo_burst[i];
+    fo = fo / (double)nb;
+    *ppm = 1e6 * (fo - target_freq) / carrier_freq;
+    const double comp_freq = target_freq - fo;
+    const double cpr = comp_freq * 2.0 * PI_D / sampling_rate;
+    st->op[op_level].type = OP_MIX;
+    st->op[op_level].param = cpr;
+    st->op[op_level].n = n;
+    return fo;
+}
+
+// FCCH_fine_correction.m:158-165,192-196
+__global__ void k_carrier_decide(StreamState* sts, int S, int ov, const double* carrier_freq, int lvl) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    const int nb = st->n_win;
+    st->n_win = 0;
+    if (nb == 0) return;
+    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 2, st->op[lvl + 1].n, &st->carrier_ppm1);
+    st->r1_kind = 3;
+    int low = 0;
+    for (int i = 0; i < nb; ++i) low += st->snr_burst[i] < 5.0;
+    if (low > 0) {                                                             // :192
+        st->n_fcch = 0;
+        st->fcch_is_sentinel = 1;
+        set_status(st, 0, GSMCAL_S_FINE_LOW_SNR);
+    }
+}
+
+// SCH_corr_rate_correction.m:8-48 -- correlation windows at level lvl
+__global__ void k_sch_setup(StreamState* sts, int S, int ov, int len_ts, int lvl, int* edge_flags) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    edge_flags[s] = 0;
+    st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0;
+    st->sampling_ppm2 = INFINITY; st->r2_kind = 0;
+    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+    if (st->status < 0) return;
+    if (st->fcch_is_sentinel || st->n_fcch < 5) { set_status(st, 1, GSMCAL_S_FEW_HITS); return; }  // :11
+    const long len_s_ov = level_len(st, lvl);
+    const long fix_off = (long)((1250 + 42) * ov);       // :26-27
+    const long max_offset = 8 * ov;                      // :36
+    int cnt = 0;
+    for (int i = 0; i < st->n_fcch; ++i) {
+        const long training_sp = (long)st->fcch_pos[i] + fix_off;
+        if (training_sp + max_offset > len_s_ov - len_ts + 1) break;           // :40
+        const long sp = training_sp - max_offset;
+        if (sp < 1) { set_status(st, 1, GSMCAL_E_INDEX); return; }
+        st->win_start[cnt++] = sp - 1;
+    }
+    st->n_win = cnt;
+}
+
+// SCH_corr_rate_correction.m:59-181
+__global__ void k_sch_decide(StreamState* sts, int S, int ov, int lvl, const int* edge_flags) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    const int num_sch = st->n_win;
+    st->n_win = 0;
+    if (st->status < 0 || st->stage_status[1] != 0) return;
+    st->n_sch_first = num_sch;
+    if (edge_flags[s]) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63
+    if (num_sch < 5) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }          // :84
+    const double frame_ov = 1250.0 * (double)ov, slot_ov = 156.25 * (double)ov;
+    const double d_ov = 10.0 * frame_ov, d1_ov = 11.0 * frame_ov;
+    const double max_ppm = 400.0;
+    const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
+    int na = 0, nb = 0;
+    unsigned a_mask = 0, b_mask = 0;
+    for (int i = 0; i < num_sch - 1; ++i) {
+        const double diff = st->sch_first[i + 1] - st->sch_first[i];
+        if (fabs(diff - d_ov) < max_th) { ++na; a_mask |= 1u << i; }
+        if (fabs(diff - d1_ov) < max_th1) { ++nb; b_mask |= 1u << i; }
+    }
+    st->r2_kind = 1;                                                           // :87 r = s
+    if (na + nb != num_sch - 1) { set_status(st, 1, GSMCAL_S_SCH_SPACING); return; }   // :106-112
+    const double expected = (double)na * d_ov + (double)nb * d1_ov;
+    const double actual = st->sch_first[num_sch - 1] - st->sch_first[0];
+    const double e = (actual - expected) / expected;
+    st->sampling_ppm2 = e * 1e6;
+    const long len_in = level_len(st, lvl);
+    long len_r = len_in;
+    if (e != 0.0) {                                                            // :120
+        len_r = e > 0.0 ? (long)floor((double)len_in / (1.0 + e)) : len_in;
+        st->op[lvl + 1].type = OP_LERP;
+        st->op[lvl + 1].param = 1.0 + e;
+    } else {
+        st->op[lvl + 1].type = OP_COPY;
+        st->op[lvl + 1].param = 1.0;
+    }
+    st->op[lvl + 1].n = len_r;
+    st->r2_kind = 2;
+    const double first = round((st->sch_first[0] - 1.0) / (1.0 + e)) + 1.0;   // :135
+    double acc = 1.0;
+    st->sch_pos[0] = acc + first - 1.0;
+    for (int i = 0; i < num_sch - 1; ++i) {
+        double step = 0.0;
+        if (a_mask & (1u << i)) step = d_ov;
+        if (b_mask & (1u << i)) step = d1_ov;
+        acc += step;
+        st->sch_pos[i + 1] = acc + first - 1.0;
+    }
+    st->n_sch = num_sch;
+    // :138-141 BCCH_flag (1-based indices 1..num_sch+1)
+    unsigned bcch = 0;
+    for (int i = 0; i < num_sch - 1; ++i)
+        if (b_mask & (1u << i)) {
+            const int b_idx = i + 1;               // 1-based
+            bcch |= 1u << (b_idx + 1);             // BCCH_flag(b_idx+1) = 1
+            if (b_idx >= 5) bcch |= 1u << (b_idx - 4);
+        }
+    const double fix_off = (double)((1250 + 42) * ov), pre_ts = (double)(42 * ov);
+    int rows = 0;
+    double* pi0 = st->pos_info;
+    double* pi1 = st->pos_info + MAXROWS;
+    for (int i = 0; i < num_sch; ++i) {
+        double sp = st->sch_pos[i] - fix_off;
+        if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 0.0; }
+        ++rows;
+        sp = st->sch_pos[i] - pre_ts;
+        double ep = sp + slot_ov - 1.0;
+        if (ep <= (double)len_r) {
+            if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 1.0; }
+            ++rows;
+        } else break;
+        const double sch_sp = sp;
+        if (bcch & (1u << (i + 1))) {
+            bool runout = false;
+            for (int idx = 1; idx <= 4; ++idx) {
+                sp = sch_sp + (double)idx * frame_ov;
+                ep = sp + slot_ov - 1.0;
+                if (ep <= (double)len_r) {
+                    if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 2.0; }
+                    ++rows;
+                } else { runout = true; break; }
+            }
+            if (runout) break;
+        }
+    }
+    if (rows > MAXROWS) { set_status(st, 1, GSMCAL_E_CAPACITY); rows = 0; }
+    st->n_rows = rows;
+}
+
+// carrier_correct_post_SCH.m:8-62 -- FCCH-row windows at level lvl
+__global__ void k_post_setup(StreamState* sts, int S, int ov, int lvl) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    st->n_win = 0; st->carrier_ppm2 = INFINITY; st->r3_kind = 0;
+    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+    if (st->status < 0) return;
+    if (st->n_rows == 0) { set_status(st, 2, GSMCAL_S_POST_NO_POS); return; }  // :10
+    const double* pi0 = st->pos_info;
+    const double* pi1 = st->pos_info + MAXROWS;
+    int nb = 0;
+    for (int i = 0; i < st->n_rows; ++i) nb += pi1[i] == 2.0;
+    if (nb < 4) { set_status(st, 2, GSMCAL_S_POST_FEW_BCCH); return; }         // :15-19
+    const int fft_len = 148 * ov;
+    const long len = level_len(st, lvl);
+    int cnt = 0;
+    for (int i = 0; i < st->n_rows; ++i)
+        if (pi1[i] == 0.0) {
+            const long sp = (long)pi0[i];
+            if (sp < 1 || sp + fft_len - 1 > len || cnt >= MAXH) { set_status(st, 2, GSMCAL_E_INDEX); return; }
+            st->win_start[cnt++] = sp - 1;
+        }
+    st->n_win = cnt;
+}
+
+// carrier_correct_post_SCH.m:75-83
+__global__ void k_post_decide(StreamState* sts, int S, int ov, const double* carrier_freq, int lvl) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    StreamState* st = sts + s;
+    const int nb = st->n_win;
+    st->n_win = 0;
+    if (nb == 0) return;
+    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 1, level_len(st, lvl), &st->carrier_ppm2);
+    st->r3_kind = 3;
+}
+
+// total_ppm_calculation.m:5-21
+__host__ __device__ inline double total_ppm(double a, double b) {
+    if (a == INFINITY && b == INFINITY) return INFINITY;
+    return ((1.0 + a * 1e-6) * (1.0 + b * 1e-6) - 1.0) * 1e6;
+}
+
+// gsm_sync_demod.m:123-124 + table row
+__global__ void k_totals(const StreamState* sts, int S, double* table, double* pos_info_out, long* r_len_out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const StreamState* st = sts + s;
+    double* row = table + (size_t)s * GSMCAL_TABLE_COLS;
+    row[GSMCAL_T_SAMPLING_PPM_FCCH] = st->sampling_ppm1;
+    row[GSMCAL_T_SAMPLING_PPM_SCH] = st->sampling_ppm2;
+    row[GSMCAL_T_CARRIER_PPM_FCCH] = st->carrier_ppm1;
+    row[GSMCAL_T_CARRIER_PPM_POST] = st->carrier_ppm2;
+    row[GSMCAL_T_TOTAL_SAMPLING_PPM] = total_ppm(st->sampling_ppm1, st->sampling_ppm2);
+    row[GSMCAL_T_TOTAL_CARRIER_PPM] = total_ppm(st->carrier_ppm1, st->carrier_ppm2);
+    row[GSMCAL_T_N_FCCH] = st->fcch_is_sentinel ? 1.0 : (double)st->n_fcch;
+    row[GSMCAL_T_N_POS_ROWS] = st->n_rows == 0 ? 1.0 : (double)st->n_rows;
+    row[GSMCAL_T_FIRST_FCCH_POS] = st->n_rows == 0 ? -1.0 : st->pos_info[0];
+    row[GSMCAL_T_STATUS] = (double)st->status;
+    if (pos_info_out) {
+        double* o = pos_info_out + (size_t)s * 2 * MAXROWS;
+        for (int i = 0; i < 2 * MAXROWS; ++i) o[i] = -1.0;
+        for (int i = 0; i < st->n_rows; ++i) { o[i] = st->pos_info[i]; o[MAXROWS + i] = st->pos_info[MAXROWS + i]; }
+    }
+    if (r_len_out) r_len_out[s] = st->r3_kind == 3 ? st->op[4].n : -1;
+}
+
+// multi_rtl_sdr_gsm_FCCH_scanner.m:168-185 acceptance -> (snr, num_hit) per capture
+__global__ void k_scan_accept(const StreamState* sts, int S, double* snr_numhit, double* positions,
+                              double* pos_snr, int* counts) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const StreamState* st = sts + s;
+    const int n = st->n_coarse;
+    double snr = 0.0, num_hit = 0.0;
+    if (n >= 3) {
+        bool ok = true;
+        for (int i = 0; i < n - 1 && ok; ++i) {
+            const double d = st->coarse_pos[i + 1] - st->coarse_pos[i];
+            if (fabs(d - 12500.0) > 50.0) ok = !(fabs(d - (12500.0 + 1250.0)) > 50.0);
+        }
+        if (ok) {
+            double sum = 0.0;
+            for (int i = 0; i < n; ++i) sum += st->coarse_snr[i];
+            snr = sum / (double)n;
+            num_hit = (double)n;
+        }
+    }
+    snr_numhit[2 * s] = snr;
+    snr_numhit[2 * s + 1] = num_hit;
+    if (counts) counts[s] = n;
+    if (positions)
+        for (int i = 0; i < MAXH; ++i) {
+            positions[(size_t)s * MAXH + i] = i < n ? st->coarse_pos[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
+            if (pos_snr) pos_snr[(size_t)s * MAXH + i] = i < n ? st->coarse_snr[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
+        }
+}

@@ -1,0 +1,295 @@
+// kernels_frontend.h -- raw bytes -> DC removal -> FIR -> (decimate | windows | whole stream).
+//
+//   k_dc_sum        raw2iq.m:8      per-stream integer sums of the I and Q bytes (exact mean)
+//   k_finish_mean                    sums -> StreamState.mean_{re,im}
+//   k_raw2iq        raw2iq.m:6-8    materialise c - mean as complex double
+//   k_fir_decim_raw gsm_sync_demod.m:107,110,117 / ..FCCH_scanner.m:132-135 fused: only the kept
+//                   rows r(1:decim:end) of filter(coef,1,raw2iq(s)) are computed
+//   k_fir_arr       filter(coef,1,s) (+ r(1:decim:end,:)) on a complex array (chn_filter_8x_4x.m:13-15)
+//   k_gather        evaluates a window (or every tile) of a stream at any level of the lazy chain
+//                   (state.h) through LDS: raw -> FIR -> lerp -> mix -> lerp -> mix
+#pragma once
+#include "state.h"
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DC sums.  grid (B, S), block 256.  Bytes at even addresses are I, odd are Q (stream start even).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dc_sum(const uint8_t* __restrict__ raw, long stream_bytes,
+                                                StreamState* __restrict__ st) {
+    const int s = blockIdx.y;
+    const uint8_t* base = raw + (size_t)s * stream_bytes;
+    const uintptr_t A = (uintptr_t)base, B = A + stream_bytes;
+    const uintptr_t a0 = (A + 15) & ~(uintptr_t)15, b0 = B & ~(uintptr_t)15;
+    unsigned int si = 0, sq = 0;  // per-thread sums: < 2^32 for any stream below 16M samples/thread
+    unsigned long long ti = 0, tq = 0;
+    if (a0 < b0) {
+        const long nvec = (long)((b0 - a0) >> 4);
+        const uint4* v = (const uint4*)a0;
+        const long per_block = (nvec + gridDim.x - 1) / gridDim.x;
+        const long v0 = (long)blockIdx.x * per_block;
+        long v1 = v0 + per_block;
+        if (v1 > nvec) v1 = nvec;
+        for (long i = v0 + threadIdx.x; i < v1; i += 256) {
+            const uint4 w = v[i];
+            // v_sad_u8(x,0,acc) = acc + sum of the 4 bytes of x
+            si = __builtin_amdgcn_sad_u8(w.x & 0x00FF00FFu, 0u, si);
+            sq = __builtin_amdgcn_sad_u8(w.x & 0xFF00FF00u, 0u, sq);
+            si = __builtin_amdgcn_sad_u8(w.y & 0x00FF00FFu, 0u, si);
+            sq = __builtin_amdgcn_sad_u8(w.y & 0xFF00FF00u, 0u, sq);
+            si = __builtin_amdgcn_sad_u8(w.z & 0x00FF00FFu, 0u, si);
+            sq = __builtin_amdgcn_sad_u8(w.z & 0xFF00FF00u, 0u, sq);
+            si = __builtin_amdgcn_sad_u8(w.w & 0x00FF00FFu, 0u, si);
+            sq = __builtin_amdgcn_sad_u8(w.w & 0xFF00FF00u, 0u, sq);
+        }
+    }
+    ti = si;
+    tq = sq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // unaligned head and tail bytes
+        const uintptr_t h1 = a0 < b0 ? a0 : B;
+        for (uintptr_t p = A; p < h1; ++p) {
+            if (p & 1) tq += *(const uint8_t*)p; else ti += *(const uint8_t*)p;
+        }
+        if (a0 < b0)
+            for (uintptr_t p = b0; p < B; ++p) {
+                if (p & 1) tq += *(const uint8_t*)p; else ti += *(const uint8_t*)p;
+            }
+    }
+    // wave reduction then one atomic per wave (integer: order independent, exact)
+    for (int off = 32; off > 0; off >>= 1) {
+        ti += __shfl_down(ti, off, 64);
+        tq += __shfl_down(tq, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&st[s].sum_i, ti);
+        atomicAdd(&st[s].sum_q, tq);
+    }
+}
+
+// raw2iq.m:8  mean = sum(c,1)./size(c,1) : exact integer sums divided once in double
+__global__ void k_finish_mean(StreamState* st, int S) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double n = (double)st[s].n0;
+    st[s].mean_re = (double)st[s].sum_i / n;
+    st[s].mean_im = (double)st[s].sum_q / n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw2iq materialised: out[n] = (I - mean_re) + 1i (Q - mean_im).  grid (B, S).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raw2iq(const uint8_t* __restrict__ raw, long stream_bytes,
+                                                const StreamState* __restrict__ st,
+                                                cplx* __restrict__ out, long out_stride) {
+    const int s = blockIdx.y;
+    const uint8_t* base = raw + (size_t)s * stream_bytes;
+    const long n = stream_bytes >> 1;
+    const double mr = st[s].mean_re, mi = st[s].mean_im;
+    cplx* o = out + (size_t)s * out_stride;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const uchar2 b = *(const uchar2*)(base + 2 * i);
+        o[i] = make_double2((double)b.x - mr, (double)b.y - mi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused front end with decimation: y[j] = f[j*decim], f = filter(coef,1,raw2iq(raw)).
+// grid (ceil(Nd/256), S), block 256.  LDS: the block's raw span (decim*256 + ntaps samples).
+// Sum order follows filter()'s transposed direct form: oldest tap first, newest last.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict__ raw, long stream_bytes,
+                                                       const StreamState* __restrict__ st,
+                                                       const double* __restrict__ coef, int ntaps,
+                                                       int decim, long nd, cplx* __restrict__ out,
+                                                       long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* c_s = (double*)smem;                                      // ntaps doubles
+    unsigned short* r_s = (unsigned short*)(smem + ((ntaps * 8 + 15) & ~15));  // raw samples (I | Q<<8)
+    const int s = blockIdx.y;
+    const long n = stream_bytes >> 1;
+    const unsigned short* base = (const unsigned short*)(raw + (size_t)s * stream_bytes);
+    const long j0 = (long)blockIdx.x * 256;
+    if (j0 >= nd) return;
+    long jn = nd - j0;
+    if (jn > 256) jn = 256;
+    const long first = j0 * decim - (ntaps - 1);            // first sample index needed (may be < 0)
+    const long last = (j0 + jn - 1) * decim;                // last sample index needed
+    const int span = (int)(last - first + 1);
+    for (int i = threadIdx.x; i < ntaps; i += 256) c_s[i] = coef[i];
+    for (int i = threadIdx.x; i < span; i += 256) {
+        const long g = first + i;
+        r_s[i] = (g >= 0 && g < n) ? base[g] : (unsigned short)0;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= jn) return;
+    const double mr = st[s].mean_re, mi = st[s].mean_im;
+    const long i_out = (j0 + t) * decim;                     // sample index of this output
+    double ar = 0.0, ai = 0.0;
+    for (int k = ntaps - 1; k >= 0; --k) {
+        const long g = i_out - k;
+        if (g < 0) continue;                                 // zero initial state
+        const unsigned short v = r_s[g - first];
+        const double c = c_s[k];
+        ar = fma(c, (double)(v & 0xFF) - mr, ar);
+        ai = fma(c, (double)(v >> 8) - mi, ai);
+    }
+    out[(size_t)s * out_stride + j0 + t] = make_double2(ar, ai);
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter(coef,1,s) on a complex array, keeping rows 1:decim:end.  grid (ceil(nd/256), D).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fir_arr(const cplx* __restrict__ in, long in_stride, long n,
+                                                 const double* __restrict__ coef, int ntaps, int decim,
+                                                 long nd, cplx* __restrict__ out, long out_stride) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nd) return;
+    const cplx* x = in + (size_t)blockIdx.y * in_stride;
+    const long i_out = j * decim;
+    double ar = 0.0, ai = 0.0;
+    for (int k = ntaps - 1; k >= 0; --k) {
+        const long g = i_out - k;
+        if (g < 0) continue;
+        const cplx v = x[g];
+        const double c = coef[k];
+        ar = fma(c, v.x, ar);
+        ai = fma(c, v.y, ai);
+    }
+    out[(size_t)blockIdx.y * out_stride + j] = make_double2(ar, ai);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gather: evaluate [start, start+len) of level `level` of every stream's lazy chain.
+//   list mode : window w of stream s starts at st[s].win_start[w]   (grid.x = max windows)
+//   tile mode : window w starts at w*len                            (grid.x = ceil(max n / len))
+// LDS: two ping-pong buffers of (len+8) complex doubles + the raw bytes for SRC_RAW.
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    int src_kind, level, len, tiles, ntaps, pad;
+    const uint8_t* raw; long raw_stride;     // bytes per stream
+    const cplx* arr;    long arr_stride;     // elements per stream
+    const double* coef;
+    cplx* dst; long dst_stream_stride, dst_win_stride;
+};
+
+__device__ __forceinline__ long level_len(const StreamState* st, int level) {
+    return level == 0 ? st->n0 : st->op[level].n;
+}
+
+__global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bufn = a.len + 8;
+    cplx* buf0 = (cplx*)smem;
+    cplx* buf1 = buf0 + bufn;
+    double* c_s = (double*)(buf1 + bufn);
+    unsigned short* r_s = (unsigned short*)(c_s + ((a.ntaps + 1) & ~1));
+    const int s = blockIdx.y;
+    const StreamState* st = sts + s;
+    const int level = a.level;
+    long start, L;
+    cplx* dst;
+    if (a.tiles) {
+        const long nq = level_len(st, level);
+        start = (long)blockIdx.x * a.len;
+        if (start >= nq) return;
+        L = nq - start < a.len ? nq - start : a.len;
+        dst = a.dst + (size_t)s * a.dst_stream_stride + start;
+    } else {
+        if ((int)blockIdx.x >= st->n_win) return;
+        start = st->win_start[blockIdx.x];
+        L = a.len;
+        dst = a.dst + (size_t)s * a.dst_stream_stride + (size_t)blockIdx.x * a.dst_win_stride;
+    }
+    // backward range propagation
+    long lo[NLEVELS], hi[NLEVELS];
+    lo[level] = start;
+    hi[level] = start + L - 1;
+    for (int j = level; j >= 1; --j) {
+        if (st->op[j].type == OP_LERP) {
+            const double f = st->op[j].param;
+            const long nprev = level_len(st, j - 1);
+            lo[j - 1] = (long)floor((double)lo[j] * f);
+            long h = (long)floor((double)hi[j] * f) + 1;
+            hi[j - 1] = h > nprev - 1 ? nprev - 1 : h;
+        } else {
+            lo[j - 1] = lo[j];
+            hi[j - 1] = hi[j];
+        }
+    }
+    // ---- level 0 ----
+    const long lo0 = lo[0], hi0 = hi[0];
+    const int cnt0 = (int)(hi0 - lo0 + 1);
+    cplx* out0 = (level == 0) ? dst : buf0;
+    if (a.src_kind == SRC_ARR) {
+        const cplx* x = a.arr + (size_t)s * a.arr_stride;
+        const long n0 = st->n0;
+        for (int i = threadIdx.x; i < cnt0; i += 256) {
+            const long g = lo0 + i;
+            out0[i] = (g >= 0 && g < n0) ? x[g] : make_double2(0.0, 0.0);
+        }
+    } else {
+        const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
+        const long n0 = st->n0;
+        const long first = lo0 - (a.ntaps - 1);
+        const int span = cnt0 + a.ntaps - 1;
+        for (int i = threadIdx.x; i < a.ntaps; i += 256) c_s[i] = a.coef[i];
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const long g = first + i;
+            r_s[i] = (g >= 0 && g < n0) ? base[g] : (unsigned short)0;
+        }
+        __syncthreads();
+        const double mr = st->mean_re, mi = st->mean_im;
+        for (int i = threadIdx.x; i < cnt0; i += 256) {
+            const long g_out = lo0 + i;
+            double ar = 0.0, ai = 0.0;
+            for (int k = a.ntaps - 1; k >= 0; --k) {
+                const long g = g_out - k;
+                if (g < 0 || g >= n0) continue;  // zero initial state
+                const unsigned short v = r_s[g - first];
+                const double c = c_s[k];
+                ar = fma(c, (double)(v & 0xFF) - mr, ar);
+                ai = fma(c, (double)(v >> 8) - mi, ai);
+            }
+            out0[i] = make_double2(ar, ai);
+        }
+    }
+    // ---- levels 1..level ----
+    cplx* src = buf0;
+    cplx* other = buf1;
+    for (int j = 1; j <= level; ++j) {
+        __syncthreads();
+        cplx* o = (j == level) ? dst : other;
+        const int cnt = (int)(hi[j] - lo[j] + 1);
+        const int type = st->op[j].type;
+        const double p = st->op[j].param;
+        const long plo = lo[j - 1], phi_ = hi[j - 1];
+        if (type == OP_LERP) {
+            for (int i = threadIdx.x; i < cnt; i += 256) {
+                const long k = lo[j] + i;
+                const double xq = (double)k * p;            // interp_seq = (0:max_len-1)'.*(1+e)
+                const long i0 = (long)floor(xq);
+                const long i1 = i0 + 1 > phi_ ? phi_ : i0 + 1;  // beyond the last sample the weight is 0
+                const double t = xq - (double)i0;
+                const cplx v0 = src[i0 - plo], v1 = src[i1 - plo];
+                o[i] = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
+            }
+        } else if (type == OP_MIX) {
+            for (int i = threadIdx.x; i < cnt; i += 256) {
+                const long k = lo[j] + i;
+                double sn, cs;
+                sincos((double)k * p, &sn, &cs);            // exp(1i*(0:len-1)'*comp_phase_rotate)
+                o[i] = cmul(src[i], make_double2(cs, sn));
+            }
+        } else {
+            for (int i = threadIdx.x; i < cnt; i += 256) o[i] = src[i];
+        }
+        cplx* tmp = src; src = other; other = tmp;
+        (void)tmp;
+    }
+}

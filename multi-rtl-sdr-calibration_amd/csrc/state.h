@@ -1,0 +1,84 @@
+// state.h -- per-stream device state shared by every kernel of the calibration chain.
+//
+// One StreamState per stream (dongle capture) lives in HBM.  The chain is a fixed sequence of
+// kernel launches; every data-dependent decision of the reference (how many hits, where the windows
+// are, which sentinel to return) is taken on the device by the `decide` kernels and stored here, so
+// the host never synchronises in the middle of the chain.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gsmcal.h"
+
+#define MAXH GSMCAL_MAX_HITS
+#define MAXROWS GSMCAL_MAX_POS_ROWS
+
+// A stream is evaluated lazily through a chain of up to 4 single-operation levels on top of level 0.
+//   level 0 : the filtered stream  f[i] = sum_k coef[k]*(raw[i-k]-mean)   (SRC_RAW)
+//             or a complex-double array handed in through the API          (SRC_ARR)
+//   OP_LERP : L[k] = lerp(L_prev, k*f)        interp1(...,'linear') of FCCH_fine_correction.m:123-125
+//                                             and SCH_corr_rate_correction.m:126-127
+//   OP_MIX  : L[k] = L_prev[k]*exp(1i*k*phi)  FCCH_fine_correction.m:165, carrier_correct_post_SCH.m:83
+//   OP_COPY : L[k] = L_prev[k]                (SCH resample skipped when e == 0, :120)
+enum { OP_NONE = 0, OP_LERP = 1, OP_MIX = 2, OP_COPY = 3 };
+enum { SRC_ARR = 0, SRC_RAW = 1 };
+#define NLEVELS 5  // level 0 + 4 ops
+
+struct LevelOp {
+    int type;      // OP_*
+    int pad;
+    double param;  // OP_LERP: (1+e); OP_MIX: comp_phase_rotate
+    long n;        // length of this level's stream
+};
+
+struct StreamState {
+    // ---- level chain ----
+    long n0;                 // length of level 0
+    unsigned long long sum_i, sum_q;  // integer byte sums (raw sources)
+    double mean_re, mean_im;
+    LevelOp op[NLEVELS];     // op[0] unused (level 0), op[1..4]
+    // ---- coarse (FCCH_coarse_position) ----
+    int n_coarse;            // number of coarse hits (0 = none found)
+    int coarse_hit_flag;     // move_fft hit flag
+    double coarse_pos[MAXH]; // 1x-symbol units, 1-based (after (p-1)*dec+1)
+    double coarse_snr[MAXH];
+    double hit_avg_snr;
+    double mv_hit_idx, mv_hit_snr;   // raw outputs of move_fft_snr_runtime_avg
+    // ---- generic window list consumed by k_gather / k_slide_dft / k_tone / k_sch_corr ----
+    int n_win;
+    long win_start[MAXH];    // 0-based start index at the window's level
+    // ---- fine search ----
+    int n_fine;              // last_idx
+    double fine_first[MAXH]; // first-round FCCH_pos (8x units, 1-based)
+    int n_fcch;              // length(FCCH_pos) returned
+    int fcch_is_sentinel;    // FCCH_pos == -1 (scalar sentinel)
+    double fcch_pos[MAXH];
+    double sampling_ppm1, carrier_ppm1;
+    double fo_burst[MAXH], snr_burst[MAXH];
+    int r1_kind;             // what FCCH_fine_correction returns as r: 0 = -1, 1 = s, 2 = lerp only, 3 = lerp+mix
+    // ---- SCH ----
+    int n_sch_first;
+    double sch_first[MAXH];
+    int n_sch;
+    double sch_pos[MAXH];
+    double sampling_ppm2;
+    int r2_kind;             // r of SCH_corr_rate_correction: 0 = -1, 1 = s, 2 = resampled (or s when e==0)
+    int n_rows;              // rows of pos_info (0 => sentinel)
+    double pos_info[2 * MAXROWS];   // column-major, ld = MAXROWS
+    // ---- post SCH ----
+    double carrier_ppm2;
+    int r3_kind;             // r of carrier_correct_post_SCH: 0 = -1, 3 = mixed
+    // ---- bookkeeping ----
+    int status;              // first non-zero status met
+    int stage_status[4];     // per reference function: fine, sch, post, coarse
+};
+
+struct PeakOut {  // partial result of k_slide_dft for one (window, bin-block)
+    double p;     // best |X|^2
+    int tie;      // tie-break key: shift index m (fine search) or fftshift-ed bin index (spectrum)
+    int k;        // bin index (unshifted)
+};
+
+__host__ __device__ inline void set_status(StreamState* s, int stage, int code) {
+    if (s->stage_status[stage] == 0) s->stage_status[stage] = code;
+    if (s->status == 0) s->status = code;
+}
