@@ -220,13 +220,13 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const int tb = 64, gb = (S + tb - 1) / tb;
     LAUNCH(c, k_fine_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.fine_wlen * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.fine_wlen, g.nfft, 0, peaks, H, g.NB);
+    LAUNCH(c, k_slide_dft<0>, dim3(g.NB, H, S), dim3(256), (size_t)g.fine_wlen * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.fine_wlen, g.nfft, peaks, H, g.NB);
     LAUNCH(c, k_fine_decide, dim3(gb), dim3(tb), 0, st, S, (const PeakOut*)peaks, H, g.NB, g.ov, lvl);
     // bursts of the resampled (not yet derotated) stream: level lvl+1
     RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, 1, peaks, H, g.NB);
+    LAUNCH(c, k_slide_dft<1>, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, peaks, H, g.NB);
     const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
            (const PeakOut*)peaks, H, g.NB, g.ov, 1);
@@ -265,8 +265,8 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const int tb = 64, gb = (S + tb - 1) / tb;
     LAUNCH(c, k_post_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, 1, peaks, H, g.NB);
+    LAUNCH(c, k_slide_dft<1>, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
+           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, peaks, H, g.NB);
     const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
            (const PeakOut*)peaks, H, g.NB, g.ov, 0);

@@ -239,10 +239,14 @@ __global__ void __launch_bounds__(256) k_coarse(StreamState* __restrict__ sts, C
 // which reproduces MATLAB's first-max rule of max(max(|fft|^2)) over windows (:50-52) and of
 // max(fftshift-ed spectrum) (:149-150).
 // ------------------------------------------------------------------------------------------------
+// SHIFTED_KEY = 0: k_slide_dft<0> is the fine search (key = window start); 1: burst spectrum argmax
+// in fftshift order (wlen == nfft, a single window).
+template <int SHIFTED_KEY>
 __global__ void __launch_bounds__(256) k_slide_dft(const StreamState* __restrict__ sts,
                                                    const cplx* __restrict__ win, long win_stream_stride,
-                                                   long win_stride, int wlen, int nfft, int shifted_key,
+                                                   long win_stride, int wlen, int nfft,
                                                    PeakOut* __restrict__ out, int H, int NB) {
+    constexpr int shifted_key = SHIFTED_KEY;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx* d = (cplx*)smem;                      // wlen differences
     __shared__ double red_p[4];

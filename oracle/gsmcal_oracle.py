@@ -56,6 +56,15 @@ def fir1(n, wn):
     return firwin(n + 1, wn, window="hamming", pass_zero=True, scale=True)
 
 
+def _seq_mean(v):
+    """mean of a short real vector as sum(v)/n with a left-to-right sum (MATLAB's order for short
+    vectors; NumPy's pairwise/unrolled sum would associate differently)."""
+    acc = 0.0
+    for x in np.asarray(v, dtype=np.float64).ravel():
+        acc += float(x)
+    return acc / len(v)
+
+
 def load_num(path):
     """Read a *_num.txt tap fixture (tests/golden)."""
     return np.loadtxt(path, dtype=np.float64, comments="#")
@@ -75,7 +84,11 @@ def raw2iq(a):
     if squeeze:
         a = a[:, None]
     c = a[0::2, :] + 1j * a[1::2, :]
-    b = c - (np.sum(c, axis=0) / c.shape[0])[None, :]
+    # sum(c,1)./size(c,1): MATLAB divides a complex by a REAL scalar part by part.  (NumPy would promote
+    # the divisor to complex and multiply by its reciprocal -- a last-bit difference -- so divide explicitly.)
+    tot = np.sum(c, axis=0)
+    mean = tot.real / c.shape[0] + 1j * (tot.imag / c.shape[0])
+    b = c - mean[None, :]
     return b[:, 0] if squeeze else b
 
 
@@ -254,7 +267,8 @@ def _fcch_tone_estimate(r, pos, fft_len, sampling_rate):
     fcch_mat = fcch_mat * np.exp(-1j * (n * int_phase_rotate[None, :]))
     ang = np.angle(fcch_mat)
     pr = np.exp(1j * ang[1:, :]) / np.exp(1j * ang[:-1, :])
-    phase_rotate = np.angle(np.mean(pr, axis=0))
+    tot = np.sum(pr, axis=0)   # mean(.,1) = sum ./ n, complex ./ real part by part
+    phase_rotate = np.arctan2(tot.imag / pr.shape[0], tot.real / pr.shape[0])
     fo = sampling_rate * (int_phase_rotate + phase_rotate) / (2.0 * np.pi)
     return fcch_mat, int_phase_rotate, phase_rotate, fo
 
@@ -356,7 +370,7 @@ def FCCH_fine_correction(s, base_position, oversampling_ratio, carrier_freq, inf
         target_freq = symbol_rate / 4
         if info is not None:
             info["fo_per_burst"] = fo.copy()
-        fo = np.mean(fo)
+        fo = _seq_mean(fo)
         carrier_ppm = 1e6 * (fo - target_freq) / carrier_freq
         comp_freq = target_freq - fo
         comp_phase_rotate = comp_freq * 2 * np.pi / sampling_rate
@@ -518,7 +532,7 @@ def carrier_correct_post_SCH(s, pos_info, oversampling_ratio, carrier_freq, info
     _, _, _, fo = _fcch_tone_estimate(s, fcch_pos, fft_len, sampling_rate)
     if info is not None:
         info["fo_per_burst"] = fo.copy()
-    fo = np.mean(fo)
+    fo = _seq_mean(fo)
     carrier_ppm = 1e6 * (fo - target_freq) / carrier_freq
     comp_freq = target_freq - fo
     comp_phase_rotate = comp_freq * 2 * np.pi / sampling_rate
@@ -578,10 +592,10 @@ def scanner_accept(FCCH_pos, FCCH_snr):
         d = np.diff(FCCH_pos)
         a = np.abs(d - 12500) > 50
         if not np.sum(a):
-            return float(np.mean(FCCH_snr)), float(len(FCCH_pos))
+            return float(_seq_mean(FCCH_snr)), float(len(FCCH_pos))
         b = np.abs(d[a] - (12500 + 1250)) > 50
         if not np.sum(b):
-            return float(np.mean(FCCH_snr)), float(len(FCCH_pos))
+            return float(_seq_mean(FCCH_snr)), float(len(FCCH_pos))
     return 0.0, 0.0
 
 

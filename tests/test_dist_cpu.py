@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the multi-GPU layer: block-contiguous sharding of units and the single
+all-gather of the per-unit table (on the GPU box the same code runs over RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _unit_row(u, cols):
+    return np.array([u * 100.0 + c for c in range(cols)])
+
+
+def _worker(rank, world, num_units, port, q):
+    sys.path.insert(0, ROOT)
+    import gsmcal
+    from gsmcal import dist as gd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = gd.shard_range(num_units, world, rank)
+    local = torch.tensor(np.stack([_unit_row(u, gsmcal.TABLE_COLS) for u in range(lo, hi)]).reshape(hi - lo, gsmcal.TABLE_COLS))
+    full = gd.allgather_table(local, num_units)
+    q.put((rank, full.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_units", [8, 7])
+def test_allgather_table_world2(num_units):
+    import gsmcal
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + num_units
+    procs = [ctx.Process(target=_worker, args=(r, world, num_units, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_unit_row(u, gsmcal.TABLE_COLS) for u in range(num_units)])
+    for r in range(world):
+        assert np.array_equal(res[r], want)
+
+
+def test_shard_ranges_cover_all_units():
+    from gsmcal import dist as gd
+    for u in (1, 7, 64, 102400):
+        for w in (1, 2, 3, 8):
+            spans = [gd.shard_range(u, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == u
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(gd.shard_sizes(u, w)) - min(gd.shard_sizes(u, w)) <= 1
+
+
+def test_sampling_phase_difference():
+    from gsmcal import dist as gd
+    a = np.array([[100.0, 0], [10100.0, 1], [20100.0, 2]])
+    b = np.array([[103.0, 0], [10103.0, 1]])
+    assert np.array_equal(gd.sampling_phase_difference(a, b), [3.0, 3.0])

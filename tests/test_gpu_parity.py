@@ -1,0 +1,327 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Bars: integer positions bit-exact; ppm within 1e-6 relative (+1e-9 ppm
+absolute floor where the oracle value is ~0); reported SNRs within 1e-8 dB; corrected streams
+within 2e-8 of their peak magnitude (the derotation exp(1i*k*c) turns a ~1e-14 relative difference in the
+estimated tone frequency into k*c*1e-14 ~ 1e-9 rad at k = 1e6, so streams cannot agree tighter than that)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import parity
+from oracle import gsmcal_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FC = 957.4e6
+STREAM_RTOL = 2e-8
+
+
+@pytest.fixture(scope="module")
+def g(gsmcal_mod, ctx):
+    return gsmcal_mod
+
+
+@pytest.fixture(scope="module")
+def setup(g):
+    s = g.synth
+    return {"coef": s.fir1(46, 200e3 / s.FS), "coef30": s.fir1(30, 200e3 / s.FS), "ts": s.sch_training_sequence(),
+            "num": o.load_num(os.path.join(HERE, "golden", "gsm_chn_filter_8x_num.txt"))}
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "calib_golden.json")) as f:
+        return json.load(f)
+
+
+def stream_close(a, b):
+    assert isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.shape == b.shape, (np.shape(a), np.shape(b))
+    scale = np.max(np.abs(b))
+    err = np.max(np.abs(a - b))
+    assert err <= STREAM_RTOL * scale, f"stream mismatch: max abs err {err} at scale {scale}"
+
+
+# ---- a1 / a2: front end ------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(1000, 1), (4099, 3), (20000, 2)])
+def test_raw2iq_bit_exact(g, n, d):
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 256, size=(2 * n, d), dtype=np.uint8)
+    want = o.raw2iq(a.astype(np.float64))
+    assert np.array_equal(g.raw2iq(a), want)                       # uint8 as it comes off the wire
+    assert np.array_equal(g.raw2iq(a.astype(np.float64)), want)    # doubles holding byte values (fread)
+    assert np.array_equal(g.raw2iq(a[:, 0]), want[:, 0])           # vector in, vector out
+
+
+def test_chn_filter_8x_4x_matches_oracle(g, setup):
+    rng = np.random.default_rng(5)
+    s = rng.standard_normal((5001, 2)) + 1j * rng.standard_normal((5001, 2))
+    want = o.chn_filter_8x_4x(s, setup["num"])
+    got = g.chn_filter_8x_4x(s)                    # built-in taps == the .fda numerator
+    assert got.shape == want.shape == (2501, 2)
+    assert np.max(np.abs(got - want)) < 1e-13
+    assert np.max(np.abs(g.chn_filter_8x_4x(s, setup["num"]) - want)) < 1e-13
+
+
+def test_driver_front_end_filter_and_decimation(g, setup):
+    # gsm_sync_demod.m:107,110,117: r = raw2iq(s); r = filter(coef,1,r); r(1:64:end,i)
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=8)[0] for d in (0, 1)])
+    r = o.matlab_filter(setup["coef"], o.raw2iq(raw.T.astype(np.float64)))
+    got = g.frontend_batch(raw, setup["coef"], 64)
+    assert got.shape == (2, 1250)
+    assert np.max(np.abs(got.T - r[0::64])) < 1e-12
+    full = g.frontend_batch(raw, setup["coef"], 1)
+    assert np.max(np.abs(full.T - r)) < 1e-12
+    assert np.max(np.abs(g.filter(setup["coef"], o.raw2iq(raw.T.astype(np.float64))) - r)) < 1e-12
+
+
+# ---- a3 / a4 / a5: coarse detector -------------------------------------------------------------
+def _coarse_input(g, setup, dongle, frames=102, coef="coef", **kw):
+    raw, _ = g.synth.make_stream(dongle=dongle, num_frames=frames, **kw)
+    r = o.matlab_filter(setup[coef], o.raw2iq(raw.astype(np.float64)))
+    return raw, r
+
+
+def test_move_fft_snr_runtime_avg(g, setup):
+    _, r = _coarse_input(g, setup, 0)
+    s = r[0::64][:3594]
+    want = o.move_fft_snr_runtime_avg(s, 160, 16, 10)
+    got = g.move_fft_snr_runtime_avg(s, 160, 16, 10)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert abs(got[2] - want[2]) < parity.SNR_ATOL and abs(got[3] - want[3]) < parity.SNR_ATOL
+    # other fft lengths go through the generic DFT path
+    want8 = o.move_fft_snr_runtime_avg(s, 80, 8, 6)
+    got8 = g.move_fft_snr_runtime_avg(s, 80, 8, 6)
+    assert got8[:2] == want8[:2] and abs(got8[3] - want8[3]) < parity.SNR_ATOL
+    # no hit: sentinel [false, -1, inf, inf]
+    noise = np.random.default_rng(0).standard_normal(600) + 1j * np.random.default_rng(1).standard_normal(600)
+    assert g.move_fft_snr_runtime_avg(noise, 160, 16, 10) == (False, -1, math.inf, math.inf)
+
+
+def test_specific_fft_snr_fix_avg(g, setup):
+    _, r = _coarse_input(g, setup, 0)
+    s = r[0::64]
+    pos, _ = o.FCCH_coarse_position(s, 8)
+    p = int((pos[1] - 1) / 8 + 1)
+    for avg in (-3.0, 50.0):
+        want = o.specific_fft_snr_fix_avg(s, (p - 5, p + 5), 16, 10, avg)
+        got = g.specific_fft_snr_fix_avg(s, (p - 5, p + 5), 16, 10, avg)
+        assert got[:2] == want[:2]
+        assert (math.isinf(want[2]) and math.isinf(got[2])) or abs(got[2] - want[2]) < parity.SNR_ATOL
+    with pytest.raises(g.GsmcalError):       # MATLAB index error -> GSMCAL_E_INDEX, never an OOB read
+        g.specific_fft_snr_fix_avg(s, (0, 5), 16, 10, 0.0)
+
+
+@pytest.mark.parametrize("dongle,frames,coef", [(0, 102, "coef"), (3, 102, "coef"), (50, 64, "coef30")])
+def test_FCCH_coarse_position(g, setup, dongle, frames, coef):
+    _, r = _coarse_input(g, setup, dongle, frames, coef)
+    want_p, want_s = o.FCCH_coarse_position(r[0::64], 8)
+    got_p, got_s = g.FCCH_coarse_position(r[0::64], 8)
+    parity.assert_positions(got_p, want_p, "position")
+    assert np.allclose(got_s, want_s, rtol=0, atol=parity.SNR_ATOL)
+
+
+def test_FCCH_coarse_position_no_fcch_sentinel(g, setup):
+    raw, _ = g.synth.make_stream(dongle=9, num_frames=64, bcch=False)
+    r = o.matlab_filter(setup["coef30"], o.raw2iq(raw.astype(np.float64)))
+    assert o.FCCH_coarse_position(r[0::64], 8) == (-1.0, -1.0)
+    assert g.FCCH_coarse_position(r[0::64], 8) == (-1.0, -1.0)
+
+
+# ---- a6..a9: the chain function by function, as gsm_sync_demod.m:117-124 calls it ---------------------
+@pytest.mark.parametrize("dongle", [0, 1, 3, 4])
+def test_chain_function_by_function(g, setup, dongle):
+    raw, r = _coarse_input(g, setup, dongle)
+    ts = setup["ts"]
+    # oracle
+    o_pos, _ = o.FCCH_coarse_position(r[0::64], 8)
+    o_fp, o_r1, o_sp1, o_cp1 = o.FCCH_fine_correction(r, o_pos, 8, FC)
+    o_pi, o_r2, o_sp2 = o.SCH_corr_rate_correction(o_r1, o_fp, ts, 8)
+    o_r3, o_cp2 = o.carrier_correct_post_SCH(o_r2, o_pi, 8, FC)
+    # HIP path, same call sequence
+    pos, _ = g.FCCH_coarse_position(r[0::64], 8)
+    fp, r1, sp1, cp1 = g.FCCH_fine_correction(r, pos, 8, FC)
+    pi, r2, sp2 = g.SCH_corr_rate_correction(r1, fp, ts, 8)
+    r3, cp2 = g.carrier_correct_post_SCH(r2, pi, 8, FC)
+
+    parity.assert_positions(fp, o_fp, "FCCH_pos")
+    parity.assert_ppm(sp1, o_sp1, "sampling_ppm(1)")
+    parity.assert_ppm(cp1, o_cp1, "carrier_ppm(1)")
+    parity.assert_positions(pi, o_pi if not np.all(o_pi == -1) else np.array([[-1.0, -1.0]]), "pos_info")
+    parity.assert_ppm(sp2, o_sp2, "sampling_ppm(2)")
+    parity.assert_ppm(cp2, o_cp2, "carrier_ppm(2)")
+    for got, want in ((r1, o_r1), (r2, o_r2), (r3, o_r3)):
+        if isinstance(want, np.ndarray):
+            stream_close(got, want)
+        else:
+            assert got == -1.0 and want == -1.0
+    tot = [g.total_ppm_calculation([sp1, sp2]), g.total_ppm_calculation([cp1, cp2])]
+    parity.assert_ppm(tot[0], o.total_ppm_calculation([o_sp1, o_sp2]), "total sampling ppm")
+    parity.assert_ppm(tot[1], o.total_ppm_calculation([o_cp1, o_cp2]), "total carrier ppm")
+
+
+def test_fine_correction_sentinels(g, setup):
+    _, r = _coarse_input(g, setup, 0)
+    # fewer than 5 coarse hits (FCCH_fine_correction.m:12-15)
+    fp, rr, sp, cp = g.FCCH_fine_correction(r, [10305.0, 22801.0, 35313.0], 8, FC)
+    assert fp == -1.0 and rr == -1.0 and sp == math.inf and cp == math.inf
+    # positions that are not FCCH bursts: spacing classification fails or the SNR gate trips -- same as oracle
+    bad = np.array([5000.0, 17000.0, 30000.0, 43000.0, 56000.0, 69000.0])
+    want = o.FCCH_fine_correction(r, bad, 8, FC)
+    got = g.FCCH_fine_correction(r, bad, 8, FC)
+    parity.assert_positions(got[0], want[0], "FCCH_pos (bad input)")
+    parity.assert_ppm(got[2], want[2], "sampling ppm (bad input)")
+    if isinstance(want[1], np.ndarray):
+        stream_close(got[1], want[1])
+    # a coarse hit in the first 64 symbols would index before the signal: MATLAB errors, the ABI returns E_INDEX
+    with pytest.raises(g.GsmcalError):
+        g.FCCH_fine_correction(r, [10.0, 12510.0, 25010.0, 37510.0, 50010.0], 8, FC)
+    with pytest.raises(o.MatlabIndexError):
+        o.FCCH_fine_correction(r, [10.0, 12510.0, 25010.0, 37510.0, 50010.0], 8, FC)
+
+
+def test_sch_and_post_sentinels(g, setup):
+    ts = setup["ts"]
+    pi, rr, sp = g.SCH_corr_rate_correction(-1.0, -1.0, ts, 8)          # failed fine stage upstream
+    assert pi.shape == (1, 2) and np.all(pi == -1) and rr == -1.0 and sp == math.inf
+    rr, cp = g.carrier_correct_post_SCH(-1.0, pi, 8, FC)
+    assert rr == -1.0 and cp == math.inf
+    # pos_info with fewer than 4 BCCH rows (carrier_correct_post_SCH.m:15-19)
+    rr, cp = g.carrier_correct_post_SCH(np.zeros(30000, complex), np.array([[1.0, 0], [10001.0, 1], [20001.0, 2]]), 8, FC)
+    assert rr == -1.0 and cp == math.inf
+    # SCH peak on the edge of the search window -> pos_info = [-1 -1] (SCH_corr_rate_correction.m:59-63)
+    _, r = _coarse_input(g, setup, 0)
+    o_pos, _ = o.FCCH_coarse_position(r[0::64], 8)
+    o_fp, o_r1, _, _ = o.FCCH_fine_correction(r, o_pos, 8, FC)
+    shifted = o_fp + 200.0                                               # pushes the true peak outside the window
+    want = o.SCH_corr_rate_correction(o_r1, shifted, ts, 8)
+    got = g.SCH_corr_rate_correction(o_r1, shifted, ts, 8)
+    assert np.all(want[0] == -1) and np.all(got[0] == -1) and got[0].shape == (1, 2)
+    assert got[1] == -1.0 or isinstance(want[1], np.ndarray)
+    parity.assert_ppm(got[2], want[2], "sampling ppm (edge)")
+
+
+# ---- batched hot path vs golden vectors and vs the oracle ---------------------------------------------
+def test_calibrate_batch_against_golden_vectors(g, setup, gold):
+    cases = gold["cases"]
+    raw = np.stack([g.synth.make_stream(dongle=c["dongle"], arfcn=c["arfcn"], num_frames=c["num_frames"])[0] for c in cases])
+    for c, r in zip(cases, raw):
+        assert int(np.sum(r.astype(np.uint64))) == c["raw_sum"]
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], gold["carrier_freq"])
+    det = g.last_batch_details(len(cases))
+
+    def num(v):
+        return math.inf if v == "inf" else v
+
+    for i, c in enumerate(cases):
+        orc = {"coarse_pos": np.asarray(c["coarse_pos"]), "coarse_snr": np.asarray(c["coarse_snr"]),
+               "fine_first_round_pos": np.asarray(c["fine_first_round_pos"]), "fcch_pos": np.asarray(c["fcch_pos"]),
+               "sch_first_round_pos": np.asarray(c["sch_first_round_pos"]),
+               "pos_info": np.asarray(c["pos_info"]).reshape(-1, 2),
+               "sampling_ppm": [num(v) for v in c["sampling_ppm"]], "carrier_ppm": [num(v) for v in c["carrier_ppm"]],
+               "total_sampling_ppm": num(c["total_sampling_ppm"]), "total_carrier_ppm": num(c["total_carrier_ppm"])}
+        parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+        assert out["r_len"][i] == c["r_len"]
+
+
+def test_calibrate_batch_against_live_oracle_with_stream_output(g, setup):
+    dongles = [10, 11, 12, 13, 14, 15]
+    raw = np.stack([g.synth.make_stream(dongle=d)[0] for d in dongles])
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, want_r=True)
+    det = g.last_batch_details(len(dongles))
+    n_ok = 0
+    for i in range(len(dongles)):
+        orc = o.calibrate_stream(raw[i], setup["coef"], setup["ts"], FC, keep_r=True)
+        parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+        if isinstance(orc.get("r_correct"), np.ndarray):
+            n_ok += 1
+            L = int(out["r_len"][i])
+            assert L == len(orc["r_correct"])
+            stream_close(out["r_correct"][i, :L], orc["r_correct"])
+        else:
+            assert out["r_len"][i] == -1
+    assert n_ok >= 2, "the seeded set should contain streams the reference algorithm calibrates"
+
+
+def test_scan_batch_against_golden_and_oracle(g, setup, gold):
+    scans = gold["scans"]
+    raw = np.stack([g.synth.make_stream(dongle=c["dongle"], arfcn=c["arfcn"], num_frames=c["num_frames"], bcch=c["bcch"])[0]
+                    for c in scans])
+    out = g.fcch_scan_batch(raw, setup["coef30"])
+    for i, c in enumerate(scans):
+        assert out["num_hit"][i] == c["num_hit"]
+        assert abs(out["snr"][i] - c["snr"]) < parity.SNR_ATOL
+        n = out["counts"][i]
+        if c["coarse_pos"] == [-1.0]:
+            assert n == 0 and out["positions"][i, 0] == -1.0
+        else:
+            parity.assert_positions(out["positions"][i, :n], c["coarse_pos"], "scan positions")
+            assert np.allclose(out["pos_snr"][i, :n], c["coarse_snr"], rtol=0, atol=parity.SNR_ATOL)
+        live = o.scan_capture(raw[i], setup["coef30"])
+        assert live["num_hit"] == out["num_hit"][i] and abs(live["snr"] - out["snr"][i]) < parity.SNR_ATOL
+
+
+# ---- edge cases --------------------------------------------------------------------------------------
+def test_batch_of_one_and_unaligned_lengths(g, setup):
+    # 61 frames: 2N = 1 220 000 bytes is not a multiple of 16 per stream -> exercises the unaligned DC-sum path
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=61)[0][: 2 * 609991] for d in (20, 21, 22)])
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    det = g.last_batch_details(3)
+    for i in range(3):
+        orc = o.calibrate_stream(raw[i], setup["coef"], setup["ts"], FC)
+        parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+    one = g.calibrate_batch(raw[1:2], setup["coef"], setup["ts"], FC)
+    assert np.array_equal(one["table"][0], out["table"][1], equal_nan=True)
+
+
+def test_noise_only_stream_yields_all_sentinels(g, setup):
+    rng = np.random.default_rng(7)
+    raw = np.clip(np.round(127.5 + 20 * rng.standard_normal((1, 2 * 1020000))), 0, 255).astype(np.uint8)
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    orc = o.calibrate_stream(raw[0], setup["coef"], setup["ts"], FC)
+    assert math.isinf(orc["total_sampling_ppm"]) and math.isinf(orc["total_carrier_ppm"])
+    row = out["table"][0]
+    assert np.all(np.isinf(row[:6])) and row[6] == 1 and row[7] == 1 and row[8] == -1 and row[9] > 0
+    assert out["pos_info"][0].shape == (1, 2) and np.all(out["pos_info"][0] == -1) and out["r_len"][0] == -1
+
+
+def test_too_short_capture_is_an_error_not_a_crash(g, setup):
+    raw = np.stack([g.synth.make_stream(dongle=0, num_frames=20)[0]])    # < 23 frames: s(1:3594) would not exist
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    assert out["table"][0, 9] == -5                                      # GSMCAL_E_INDEX, like MATLAB's index error
+    with pytest.raises(o.MatlabIndexError):
+        o.calibrate_stream(raw[0], setup["coef"], setup["ts"], FC)
+
+
+# ---- full BASELINE size: size-independent properties ---------------------------------------------------
+def test_full_size_batch_properties(g, setup):
+    """64 streams x 1 020 000 samples (BASELINE config 4 on one GPU): (1) every stream's row equals the
+    row it gets in a batch of its own (units are independent); (2) two runs are bit-identical;
+    (3) ppm-table mode == stream-output mode; (4) 'test on line' (FCCH_fine_correction.m:167-183):
+    re-estimating the tone on the corrected stream gives ~zero residual carrier error."""
+    distinct = np.stack([g.synth.make_stream(dongle=30 + d)[0] for d in range(8)])
+    raw = np.tile(distinct, (8, 1))
+    perm = np.random.default_rng(1).permutation(64)
+    raw = raw[perm]
+    a = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    b = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    assert np.array_equal(a["table"], b["table"], equal_nan=True)
+    singles = g.calibrate_batch(distinct, setup["coef"], setup["ts"], FC, want_r=True)
+    for i in range(64):
+        assert np.array_equal(a["table"][i], singles["table"][perm[i] % 8], equal_nan=True)
+    ok = [i for i in range(8) if singles["table"][i, 9] == 0]
+    assert ok, "seeded set must contain calibratable streams"
+    for i in ok:
+        L = int(singles["r_len"][i])
+        r = singles["r_correct"][i, :L]
+        pi = singles["pos_info"][i]
+        r_again, resid = g.carrier_correct_post_SCH(r, pi, 8, FC)
+        assert abs(resid) < 1e-6, f"residual carrier ppm after correction: {resid}"
+        # and the oracle agrees on one of them (cheap: windows only)
+    orc = o.calibrate_stream(distinct[ok[0]], setup["coef"], setup["ts"], FC)
+    parity.assert_ppm(singles["table"][ok[0], 4], orc["total_sampling_ppm"], "total sampling ppm")
+    parity.assert_ppm(singles["table"][ok[0], 5], orc["total_carrier_ppm"], "total carrier ppm")
