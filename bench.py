@@ -159,12 +159,12 @@ def main():
             dom = max(tot, key=tot.get)
             avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
             out["kernels_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-            nfft, wlen = 148 * 8, 128 * 8 + 148 * 8
+            nfft, nstep = 148 * 8, 128 * 8   # FCCH_fine_correction.m:20-21,30: 1184 bins, 1024 slides per window
             n_fine_windows = int(np.sum(det["counts"][:, 1])) * (D // nd) if D % nd == 0 else None
             if n_fine_windows is None:
                 n_fine_windows = int(round(np.mean(det["counts"][:, 1]) * D))
-            if dom.startswith("k_slide_dft<0>"):
-                flops = n_fine_windows * nfft * wlen * FLOP_PER_BIN_STEP
+            if dom == "k_fine_search":
+                flops = n_fine_windows * nfft * nstep * FLOP_PER_BIN_STEP
                 ach = flops / (avg_ms[dom] * 1e-3) / 1e12
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": F64_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(ach / F64_PEAK_TFLOPS, 4), "traffic": None,
@@ -172,7 +172,7 @@ def main():
                                    "note": "fp64 compute roofline: on MI355X the f64 vector peak equals the f64 MFMA peak "
                                            "(78.6 TFLOP/s); the kernel is an element-wise sliding-DFT recurrence on the "
                                            "vector ALU (v_fma_f64), not a contraction; flops = fine windows x 1184 bins x "
-                                           "2208 steps x 11"}
+                                           "1024 slides x 11"}
             else:
                 nbytes = D * N * (2 if dom == "k_dc_sum" else 18)
                 ach = nbytes / (avg_ms[dom] * 1e-3) / 1e9

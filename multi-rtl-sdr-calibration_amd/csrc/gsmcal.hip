@@ -42,7 +42,8 @@ struct gsmcal_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
-    DevBuf state, coef, ts, cf, dec, win, peaks, edge, table, snrhit, arr_in, arr_out, posinfo, rlen, misc;
+    DevBuf state, coef, ts, cf, dec, win, peaks, edge, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, x0;
+    int tw_n = 0;                            // length the twiddle table was built for
     std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
     int last_S = 0;
     // profiling
@@ -192,7 +193,7 @@ struct Source {
 size_t gather_lds(int len, int level, int kind, int ntaps) {
     size_t bufn = (size_t)len + 8;
     size_t b = 2 * bufn * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * 8;
-    if (kind == SRC_RAW) b += (bufn + ntaps + 8) * 2;
+    if (kind == SRC_RAW) b += (bufn + ntaps + 24) * 2;
     (void)level;
     return (b + 15) & ~(size_t)15;
 }
@@ -209,27 +210,45 @@ int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, b
     return 0;
 }
 
+int ensure_twiddles(gsmcal_ctx* c, int nfft) {
+    if (c->tw_n == nfft) return 0;
+    RET_IF(ensure(c, c->tw, (size_t)nfft * sizeof(cplx)));
+    LAUNCH(c, k_make_twiddles, dim3((nfft + 255) / 256), dim3(256), 0, (cplx*)c->tw.p, nfft);
+    CHECK_LAUNCH(c);
+    c->tw_n = nfft;
+    return 0;
+}
+
+size_t fft_lds(const Geom& g) {
+    return ((size_t)2 * g.nfft + (size_t)37 * (g.nfft / 37 + 1)) * sizeof(cplx);
+}
+
 // ---- FCCH_fine_correction body (input at level lvl; creates levels lvl+1 (lerp), lvl+2 (mix)) ----
 int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H) {
     StreamState* st = (StreamState*)c->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
     RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    RET_IF(ensure(c, c->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
+    RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->win.p;
     PeakOut* peaks = (PeakOut*)c->peaks.p;
     const int tb = 64, gb = (S + tb - 1) / tb;
     LAUNCH(c, k_fine_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft<0>, dim3(g.NB, H, S), dim3(256), (size_t)g.fine_wlen * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.fine_wlen, g.nfft, peaks, H, g.NB);
+    LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->x0.p, H);
+    LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1) * sizeof(cplx),
+           (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->x0.p,
+           peaks, H, g.NB);
     LAUNCH(c, k_fine_decide, dim3(gb), dim3(tb), 0, st, S, (const PeakOut*)peaks, H, g.NB, g.ov, lvl);
     // bursts of the resampled (not yet derotated) stream: level lvl+1
     RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft<1>, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, peaks, H, g.NB);
+    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+           wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
     const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, g.NB, g.ov, 1);
+           (const PeakOut*)peaks, H, 1, g.ov, 1);
     LAUNCH(c, k_carrier_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
     CHECK_LAUNCH(c);
     return 0;
@@ -260,16 +279,17 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
     RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->win.p;
     PeakOut* peaks = (PeakOut*)c->peaks.p;
     const int tb = 64, gb = (S + tb - 1) / tb;
     LAUNCH(c, k_post_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_slide_dft<1>, dim3(g.NB, H, S), dim3(256), (size_t)g.nfft * sizeof(cplx), (const StreamState*)st,
-           (const cplx*)win, sstride, wstride, g.nfft, g.nfft, peaks, H, g.NB);
+    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+           wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
     const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, g.NB, g.ov, 0);
+           (const PeakOut*)peaks, H, 1, g.ov, 0);
     LAUNCH(c, k_post_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
     CHECK_LAUNCH(c);
     return 0;
@@ -298,7 +318,7 @@ int dc_means(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n) {
 int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                   cplx* d_out, long out_stride) {
     const long nd = (n + decim - 1) / decim;
-    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (size_t)(256 * decim + ntaps + 8) * 2;
+    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (size_t)(256 * decim + ntaps + 24) * 2;
     if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_fir_decim_raw, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
            (const StreamState*)c->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
@@ -319,8 +339,8 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
-    const size_t lds = (size_t)fft_len * sizeof(cplx) + (size_t)(n_first + 64) * sizeof(double);
-    if (lds > 64 * 1024) return GSMCAL_E_UNSUPPORTED;
+    const size_t lds = 64 * sizeof(cplx) + (size_t)(COARSE_CHUNK + n_first + 64) * sizeof(double);
+    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_coarse, dim3(S), dim3(256), lds, (StreamState*)c->state.p, a);
     CHECK_LAUNCH(c);
     return 0;
@@ -389,6 +409,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     gsmcal_ctx* c = new gsmcal_ctx();
     c->device = device_id;
     c->stream = (hipStream_t)hip_stream;
@@ -415,7 +437,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->state, &c->coef, &c->ts, &c->cf, &c->dec, &c->win, &c->peaks, &c->edge, &c->table,
-                      &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen, &c->misc};
+                      &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen, &c->misc, &c->tw, &c->x0};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -552,7 +574,7 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
         nwin_cap = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
     }
     if (fft_len < 2 || fft_len > 64) return GSMCAL_E_UNSUPPORTED;
-    const size_t lds = (size_t)fft_len * sizeof(cplx) + (size_t)(nwin_cap + 64) * sizeof(double);
+    const size_t lds = 64 * sizeof(cplx) + (size_t)(COARSE_CHUNK + nwin_cap + 64) * sizeof(double);
     if (lds > 160 * 1024 - 256) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_coarse, dim3(1), dim3(256), lds, (StreamState*)c->state.p, a);
     CHECK_LAUNCH(c);

@@ -18,6 +18,36 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage raw samples [first, first+span) of one stream (I | Q<<8 per ushort) into LDS with 16-byte
+// global loads.  Returns `first_al` <= first: sample g lives at r_s[g - first_al].  Samples outside
+// [0, n) read as 0 (filter()'s zero initial state is applied by the callers through g < 0 tests).
+// r_s must hold span + 16 ushorts and be 16-byte aligned.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long stage_raw(unsigned short* r_s, const unsigned short* base, long n, long first,
+                                          int span, int tid, int nthreads) {
+    const long ao = (long)(((uintptr_t)base >> 1) & 7);          // samples past a 16-byte boundary at g = 0
+    long m = (first + ao) % 8;
+    if (m < 0) m += 8;
+    const long first_al = first - m;                             // address of sample first_al is 16-byte aligned
+    const int nchunk = (int)((first + span - first_al + 7) >> 3);
+    for (int c = tid; c < nchunk; c += nthreads) {
+        const long g0 = first_al + 8L * c;
+        uint4 v;
+        if (g0 >= 0 && g0 + 8 <= n) {
+            v = *(const uint4*)(base + g0);
+        } else {
+            unsigned short t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = (g0 + i >= 0 && g0 + i < n) ? base[g0 + i] : (unsigned short)0;
+            v.x = t[0] | ((unsigned)t[1] << 16); v.y = t[2] | ((unsigned)t[3] << 16);
+            v.z = t[4] | ((unsigned)t[5] << 16); v.w = t[6] | ((unsigned)t[7] << 16);
+        }
+        *(uint4*)(r_s + 8 * c) = v;
+    }
+    return first_al;
+}
+
+// ------------------------------------------------------------------------------------------------
 // DC sums.  grid (B, S), block 256.  Bytes at even addresses are I, odd are Q (stream start even).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_dc_sum(const uint8_t* __restrict__ raw, long stream_bytes,
@@ -121,10 +151,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
     const long last = (j0 + jn - 1) * decim;                // last sample index needed
     const int span = (int)(last - first + 1);
     for (int i = threadIdx.x; i < ntaps; i += 256) c_s[i] = coef[i];
-    for (int i = threadIdx.x; i < span; i += 256) {
-        const long g = first + i;
-        r_s[i] = (g >= 0 && g < n) ? base[g] : (unsigned short)0;
-    }
+    const long first_al = stage_raw(r_s, base, n, first, span, threadIdx.x, 256);
     __syncthreads();
     const int t = threadIdx.x;
     if (t >= jn) return;
@@ -134,7 +161,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
     for (int k = ntaps - 1; k >= 0; --k) {
         const long g = i_out - k;
         if (g < 0) continue;                                 // zero initial state
-        const unsigned short v = r_s[g - first];
+        const unsigned short v = r_s[g - first_al];
         const double c = c_s[k];
         ar = fma(c, (double)(v & 0xFF) - mr, ar);
         ai = fma(c, (double)(v >> 8) - mi, ai);
@@ -239,10 +266,7 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
         const long first = lo0 - (a.ntaps - 1);
         const int span = cnt0 + a.ntaps - 1;
         for (int i = threadIdx.x; i < a.ntaps; i += 256) c_s[i] = a.coef[i];
-        for (int i = threadIdx.x; i < span; i += 256) {
-            const long g = first + i;
-            r_s[i] = (g >= 0 && g < n0) ? base[g] : (unsigned short)0;
-        }
+        const long first_al = stage_raw(r_s, base, n0, first, span, threadIdx.x, 256);
         __syncthreads();
         const double mr = st->mean_re, mi = st->mean_im;
         for (int i = threadIdx.x; i < cnt0; i += 256) {
@@ -251,7 +275,7 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
             for (int k = a.ntaps - 1; k >= 0; --k) {
                 const long g = g_out - k;
                 if (g < 0 || g >= n0) continue;  // zero initial state
-                const unsigned short v = r_s[g - first];
+                const unsigned short v = r_s[g - first_al];
                 const double c = c_s[k];
                 ar = fma(c, (double)(v & 0xFF) - mr, ar);
                 ai = fma(c, (double)(v >> 8) - mi, ai);
