@@ -42,7 +42,7 @@ struct gsmcal_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
-    DevBuf state, coef, ts, cf, dec, win, peaks, edge, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, x0;
+    DevBuf state, coef, ts, cf, dec, win, peaks, snrbuf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, x0;
     int tw_n = 0;                            // length the twiddle table was built for
     std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
     int last_S = 0;
@@ -159,19 +159,6 @@ int upload_cached(gsmcal_ctx* c, DevBuf& b, std::vector<double>& host, const dou
     return 0;
 }
 
-__global__ void k_init_state(StreamState* sts, int S, long n0) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
-    // zero everything, then the few non-zero defaults (sentinels of the reference functions)
-    unsigned long long* w = (unsigned long long*)st;
-    for (size_t i = 0; i < sizeof(StreamState) / 8; ++i) w[i] = 0ull;
-    st->n0 = n0;
-    st->hit_avg_snr = INFINITY;
-    st->sampling_ppm1 = st->carrier_ppm1 = st->sampling_ppm2 = st->carrier_ppm2 = INFINITY;
-    st->fcch_is_sentinel = 1;
-}
-
 struct Geom {  // burst geometry for an oversampling ratio
     int ov, nfft, fine_wlen, fine_nshift, NB, sch_nshift;
     explicit Geom(int ov_) : ov(ov_) {
@@ -191,10 +178,12 @@ struct Source {
 };
 
 size_t gather_lds(int len, int level, int kind, int ntaps) {
-    size_t bufn = (size_t)len + 8;
-    size_t b = 2 * bufn * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * 8;
-    if (kind == SRC_RAW) b += (bufn + ntaps + 24) * 2;
-    (void)level;
+    // must mirror the carve at the top of k_gather
+    const size_t bufn = level >= 1 ? (size_t)len + 8 : 0;
+    size_t b = bufn * sizeof(cplx) * (level >= 2 ? 2 : 1) + (size_t)((ntaps + 1) & ~1) * 8;
+    const size_t span_max = (size_t)len + 8 + ntaps + 24;
+    b += ((span_max + 7) & ~(size_t)7) * 2;
+    if (kind == SRC_RAW) b += (span_max + span_max / 4 + 16) * sizeof(cplx);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -223,8 +212,20 @@ size_t fft_lds(const Geom& g) {
     return ((size_t)2 * g.nfft + (size_t)37 * (g.nfft / 37 + 1)) * sizeof(cplx);
 }
 
+StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ov = g.ov; a.H = H; a.NB = g.NB; a.len_ts = len_ts;
+    a.peaks = (const PeakOut*)c->peaks.p;
+    a.carrier_freq = (const double*)c->cf.p;
+    return a;
+}
+
 // ---- FCCH_fine_correction body (input at level lvl; creates levels lvl+1 (lerp), lvl+2 (mix)) ----
-int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H) {
+// setup_done: the window setup already ran at the end of k_coarse_scan (batch path).
+// next_sch_lvl >= 0: also run SCH_corr_rate_correction's window setup in the last decision launch.
+int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, bool setup_done,
+             int next_sch_lvl, int len_ts) {
     StreamState* st = (StreamState*)c->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
@@ -233,48 +234,56 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->win.p;
     PeakOut* peaks = (PeakOut*)c->peaks.p;
-    const int tb = 64, gb = (S + tb - 1) / tb;
-    LAUNCH(c, k_fine_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
+    const StepArgs sa = step_args(c, g, H, len_ts);
+    if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->x0.p, H);
     LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1) * sizeof(cplx),
            (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->x0.p,
            peaks, H, g.NB);
-    LAUNCH(c, k_fine_decide, dim3(gb), dim3(tb), 0, st, S, (const PeakOut*)peaks, H, g.NB, g.ov, lvl);
+    LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1
     RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
-    const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
+    const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, 1, g.ov, 1);
-    LAUNCH(c, k_carrier_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
+           (const PeakOut*)peaks, H, (const cplx*)c->tw.p, g.ov, 1);
+    if (next_sch_lvl >= 0)
+        LAUNCH(c, k_step<STEP_CARRIER_DECIDE | STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_sch_lvl);
+    else
+        LAUNCH(c, k_step<STEP_CARRIER_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
 
 // ---- SCH_corr_rate_correction body (input at level lvl; creates level lvl+1) ----
-int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, int len_ts) {
+int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, int len_ts, bool setup_done,
+            int next_post_lvl) {
     StreamState* st = (StreamState*)c->state.p;
     const int wl = g.sch_nshift - 1 + len_ts;
     const long wstride = g.fine_wlen > wl ? g.fine_wlen : wl, sstride = (long)H * wstride;
     RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
-    RET_IF(ensure(c, c->edge, (size_t)S * sizeof(int)));
     cplx* win = (cplx*)c->win.p;
-    const int tb = 64, gb = (S + tb - 1) / tb;
-    LAUNCH(c, k_sch_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, len_ts, lvl, (int*)c->edge.p);
+    const StepArgs sa = step_args(c, g, H, len_ts);
+    if (!setup_done) LAUNCH(c, k_step<STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     RET_IF(launch_gather(c, S, src, lvl, wl, false, H, win, sstride, wstride));
     const size_t lds = (size_t)(wl + len_ts) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
     LAUNCH(c, k_sch_corr, dim3(H, S), dim3(128), lds, st, (const cplx*)win, sstride, wstride,
-           (const cplx*)c->ts.p, len_ts, g.sch_nshift, (int*)c->edge.p);
-    LAUNCH(c, k_sch_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl, (const int*)c->edge.p);
+           (const cplx*)c->ts.p, len_ts, g.sch_nshift, 0);
+    if (next_post_lvl >= 0)
+        LAUNCH(c, k_step<STEP_SCH_DECIDE | STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_post_lvl);
+    else
+        LAUNCH(c, k_step<STEP_SCH_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
 
 // ---- carrier_correct_post_SCH body (input at level lvl; creates level lvl+1 (mix)) ----
-int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H) {
+// table != nullptr: also write the calibration table row (gsm_sync_demod.m:123-124) in the last launch.
+int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, bool setup_done, double* table,
+             double* pos_info_out, long* r_len_out) {
     StreamState* st = (StreamState*)c->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
@@ -282,23 +291,27 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->win.p;
     PeakOut* peaks = (PeakOut*)c->peaks.p;
-    const int tb = 64, gb = (S + tb - 1) / tb;
-    LAUNCH(c, k_post_setup, dim3(gb), dim3(tb), 0, st, S, g.ov, lvl);
+    StepArgs sa = step_args(c, g, H, 0);
+    sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
+    if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
-    const size_t tone_lds = (size_t)g.nfft * (2 * sizeof(cplx) + sizeof(double));
+    const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, 1, g.ov, 0);
-    LAUNCH(c, k_post_decide, dim3(gb), dim3(tb), 0, st, S, g.ov, (const double*)c->cf.p, lvl);
+           (const PeakOut*)peaks, H, (const cplx*)c->tw.p, g.ov, 0);
+    if (table)
+        LAUNCH(c, k_step<STEP_POST_DECIDE | STEP_TOTALS>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
+    else
+        LAUNCH(c, k_step<STEP_POST_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
 
 int init_states(gsmcal_ctx* c, int S, long n0) {
+    (void)n0;   // written with the other defaults by k_finish_mean
     RET_IF(ensure(c, c->state, (size_t)S * sizeof(StreamState)));
-    LAUNCH(c, k_init_state, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S, n0);
-    CHECK_LAUNCH(c);
+    HIPCHK(c, hipMemsetAsync(c->state.p, 0, (size_t)S * sizeof(StreamState), c->stream));
     c->last_S = S;
     return 0;
 }
@@ -310,7 +323,7 @@ int dc_means(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n) {
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
     LAUNCH(c, k_dc_sum, dim3(blocks, S), dim3(256), 0, d_raw, 2 * n, (StreamState*)c->state.p);
-    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S);
+    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S, n);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -318,7 +331,8 @@ int dc_means(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n) {
 int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                   cplx* d_out, long out_stride) {
     const long nd = (n + decim - 1) / decim;
-    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (size_t)(256 * decim + ntaps + 24) * 2;
+    const size_t span = (size_t)256 * decim + ntaps + 24;
+    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
     if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_fir_decim_raw, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
            (const StreamState*)c->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
@@ -333,15 +347,24 @@ int hits_capacity(long len_dec, int dec_ratio) {
     return h;
 }
 
-int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio) {
+size_t coarse_scan_lds(long nwin, int mv_len) {
+    return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + (size_t)(nwin + mv_len + 128) * sizeof(double);
+}
+
+int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
     a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
+    a.fine_setup_ov = fine_setup_ov;
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
-    const size_t lds = 64 * sizeof(cplx) + (size_t)(COARSE_CHUNK + n_first + 64) * sizeof(double);
-    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
-    LAUNCH(c, k_coarse, dim3(S), dim3(256), lds, (StreamState*)c->state.p, a);
+    const long nwin = n_first - (fft_len - 1);
+    const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
+    if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
+    RET_IF(ensure(c, c->snrbuf, (size_t)S * nwin * sizeof(double)));
+    a.snr_g = (double*)c->snrbuf.p; a.snr_stride = nwin;
+    LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
+    LAUNCH(c, k_coarse_scan, dim3(S), dim3(256), lds, (StreamState*)c->state.p, a);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -408,7 +431,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     // kernels whose dynamic LDS may exceed the 64 KiB default
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_tone, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     gsmcal_ctx* c = new gsmcal_ctx();
@@ -436,7 +460,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->state, &c->coef, &c->ts, &c->cf, &c->dec, &c->win, &c->peaks, &c->edge, &c->table,
+    DevBuf* bufs[] = {&c->state, &c->coef, &c->ts, &c->cf, &c->dec, &c->win, &c->peaks, &c->snrbuf, &c->table,
                       &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen, &c->misc, &c->tw, &c->x0};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -565,20 +589,28 @@ int gsmcal_chn_filter_8x_4x(gsmcal_ctx* c, const double* s, long n, int d, const
 static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, StreamState* out) {
     HIPCHK(c, hipSetDevice(c->device));
     RET_IF(upload_array(c, s, (size_t)len));
-    RET_IF(init_states(c, 1, len));
+    std::vector<StreamState> v(1);
+    host_init_state(v[0], len);
+    RET_IF(push_states(c, v));
+    c->last_S = 1;
     a.s = (const cplx*)c->arr_in.p; a.s_stride = len; a.len = len;
     int fft_len = a.fft_len;
-    long nwin_cap = len;
+    long n_first = len;
     if (a.mode == 0) {
         fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
-        nwin_cap = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
+        n_first = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
     }
     if (fft_len < 2 || fft_len > 64) return GSMCAL_E_UNSUPPORTED;
-    const size_t lds = 64 * sizeof(cplx) + (size_t)(COARSE_CHUNK + nwin_cap + 64) * sizeof(double);
-    if (lds > 160 * 1024 - 256) return GSMCAL_E_UNSUPPORTED;
-    LAUNCH(c, k_coarse, dim3(1), dim3(256), lds, (StreamState*)c->state.p, a);
+    const long nwin = n_first - (fft_len - 1);
+    const size_t lds = coarse_scan_lds(n_first > 0 ? n_first : 0, a.mode == 0 ? 10 * fft_len : a.mv_len);
+    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
+    if (a.mode != 2 && nwin >= 1 && n_first <= len) {
+        RET_IF(ensure(c, c->snrbuf, (size_t)nwin * sizeof(double)));
+        a.snr_g = (double*)c->snrbuf.p; a.snr_stride = nwin;
+        LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
+    }
+    LAUNCH(c, k_coarse_scan, dim3(1), dim3(256), lds, (StreamState*)c->state.p, a);
     CHECK_LAUNCH(c);
-    std::vector<StreamState> v;
     RET_IF(fetch_states(c, 1, v));
     *out = v[0];
     return 0;
@@ -655,7 +687,7 @@ int gsmcal_FCCH_fine_correction(gsmcal_ctx* c, const double* s, long len, const 
     c->last_S = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_base > 0 ? num_base : 1;
-    RET_IF(run_fine(c, 1, src, 0, g, H));
+    RET_IF(run_fine(c, 1, src, 0, g, H, false, -1, 0));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
@@ -706,7 +738,7 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
     c->last_S = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_fcch > 0 ? num_fcch : 1;
-    RET_IF(run_sch(c, 1, src, 0, g, H, len_ts));
+    RET_IF(run_sch(c, 1, src, 0, g, H, len_ts, false, -1));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
@@ -764,7 +796,7 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, co
     RET_IF(push_states(c, v));
     c->last_S = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
-    RET_IF(run_post(c, 1, src, 0, g, nfcch > 0 ? nfcch : 1));
+    RET_IF(run_post(c, 1, src, 0, g, nfcch > 0 ? nfcch : 1, false, nullptr, nullptr, nullptr));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
@@ -828,9 +860,11 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(init_states(c, d, n));
     RET_IF(dc_means(c, d_raw, d, n));
     RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));
-    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio));
-    LAUNCH(c, k_scan_accept, dim3((d + 63) / 64), dim3(64), 0, (const StreamState*)c->state.p, d, d_snr_numhit,
-           d_positions, d_pos_snr, d_counts);
+    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio, 0));
+    StepArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.snr_numhit = d_snr_numhit; sa.positions = d_positions; sa.pos_snr = d_pos_snr; sa.counts = d_counts;
+    LAUNCH(c, k_step<STEP_SCAN_ACCEPT>, dim3(d), dim3(64), 0, (StreamState*)c->state.p, sa, 0, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -875,14 +909,11 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(init_states(c, d, n));
     RET_IF(dc_means(c, d_raw, d, n));                                                  // raw2iq.m:8
     RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));  // :107,110,117
-    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio));                    // :117
+    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio, ov));                // :117 (+ fine window setup)
     Source src{SRC_RAW, d_raw, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
-    RET_IF(run_fine(c, d, src, 0, g, H));                                              // :118
-    RET_IF(run_sch(c, d, src, 2, g, H, len_ts));                                       // :119
-    RET_IF(run_post(c, d, src, 3, g, H));                                              // :120
-    LAUNCH(c, k_totals, dim3((d + 63) / 64), dim3(64), 0, (const StreamState*)c->state.p, d, d_table, d_pos_info,
-           d_r_len);                                                                   // :123-124
-    CHECK_LAUNCH(c);
+    RET_IF(run_fine(c, d, src, 0, g, H, true, 2, len_ts));                             // :118 (+ SCH window setup)
+    RET_IF(run_sch(c, d, src, 2, g, H, len_ts, true, 3));                              // :119 (+ post-SCH window setup)
+    RET_IF(run_post(c, d, src, 3, g, H, true, d_table, d_pos_info, d_r_len));          // :120, :123-124
     if (d_r_correct) {
         const int tiles = (int)((n + TILE - 1) / TILE);
         RET_IF(launch_gather(c, d, src, 4, TILE, true, tiles, (cplx*)d_r_correct, n, 0));

@@ -124,39 +124,92 @@ struct CoarseArgs {
     int mode;      // 0 = FCCH_coarse_position, 1 = move_fft_snr_runtime_avg only, 2 = specific only
     int mv_len, fft_len; double th;           // modes 1/2 (mode 0 derives them like the reference)
     long t_lo, t_hi; double avg_snr;          // mode 2: target_set and fixed average
+    double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
+    int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
 };
 
-// grid S, block 256.  LDS: 64 twiddles | running sums of one chunk | snr[nwin].
-//
-// move_fft_snr_runtime_avg's loop is serial only through sum_snr (two dependent fp64 adds per window,
-// :37-38).  Per chunk of COARSE_CHUNK windows: (A) all lanes compute the window SNRs, (B) lane 0
-// replays the reference's running-sum updates in the reference's order and records the sum each
-// window sees, (C) all lanes evaluate snr - sum/mv_len > th (the true fp64 divide of :30) and the
-// first hit wins.  Updates past a hit inside a chunk are never used -- the same as the `break`.
-#define COARSE_CHUNK 512
-__global__ void __launch_bounds__(256) k_coarse(StreamState* __restrict__ sts, CoarseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
-    __shared__ double sh_sum;  // running sum carried between chunks
-    StreamState* st = sts + blockIdx.x;
-    const cplx* s = a.s + (size_t)blockIdx.x * a.s_stride;
-    const long len = a.len;
-    int fft_len, mv_len;
-    double th;
-    long n_first;
+struct CoarseGeom { int fft_len, mv_len; double th; long n_first, nwin; };
+
+__device__ __forceinline__ CoarseGeom coarse_geom(const CoarseArgs& a) {
+    CoarseGeom g;
     if (a.mode == 0) {
         // FCCH_coarse_position.m:15-25
-        fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
-        th = 10.0;
-        mv_len = 10 * fft_len;
-        n_first = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
+        g.fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
+        g.th = 10.0;
+        g.mv_len = 10 * g.fft_len;
+        g.n_first = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
     } else {
-        fft_len = a.fft_len; mv_len = a.mv_len; th = a.th; n_first = len;
+        g.fft_len = a.fft_len; g.mv_len = a.mv_len; g.th = a.th; g.n_first = a.len;
     }
+    g.nwin = g.n_first - (g.fft_len - 1);
+    return g;
+}
+
+__device__ __forceinline__ void coarse_twiddles(cplx* tw, int fft_len, int tid, int nthreads) {
+    if (fft_len != 16 && fft_len >= 2 && fft_len <= 64)
+        for (int i = tid; i < fft_len; i += nthreads) {
+            double sn, cs;
+            sincospi(-2.0 * (double)i / (double)fft_len, &sn, &cs);
+            tw[i] = make_double2(cs, sn);
+        }
+}
+
+// ---- k_coarse_snr: every sliding-window SNR of move_fft_snr_runtime_avg.m:17-28, all in parallel ----
+// grid (ceil(nwin/256), S), block 256.
+__global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
+    __shared__ cplx tw[64];
+    const CoarseGeom g = coarse_geom(a);
+    if (g.fft_len > 64 || g.fft_len < 2 || g.n_first > a.len) return;   // the scan kernel reports the index error
+    coarse_twiddles(tw, g.fft_len, threadIdx.x, 256);
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.nwin) return;
+    const cplx* s = a.s + (size_t)blockIdx.y * a.s_stride;
+    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s + i, g.fft_len, tw);
+}
+
+__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl);   // kernels_estim.h
+
+// ---- k_coarse_scan: the serial part of the detector, one workgroup per stream ----
+// grid S, block 256.  LDS: state copy | 64 twiddles | snr[nwin].
+//
+// move_fft_snr_runtime_avg's loop is serial only through sum_snr (two dependent fp64 adds per window,
+// :37-38).  Wave 0 replays the reference's running-sum updates in the reference's order, 64 windows
+// at a time: every lane advances the same (wave-uniform) sum from broadcast LDS reads, lane j keeps
+// the sum window j sees, then the 64 lanes evaluate snr - sum/mv_len > th (the true fp64 divide of
+// :30) and a ballot picks the first hit.  Updates past a hit are never used -- the `break`.
+// Then the hop loop of FCCH_coarse_position.m:32-86 (both the +10-frame and the +11-frame candidate
+// windows of a hop are evaluated together; the +11 ones are only consulted when the +10 ones miss).
+__global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
+    __shared__ double sh_avg;  // sum/mv_len seen by the hit window
+    StreamState* st = (StreamState*)smem;                 // LDS copy of the stream state
+    cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
+    double* snr_s = (double*)(tw + 64);
+    StreamState* st_g = sts + blockIdx.x;
+    const cplx* s = a.s + (size_t)blockIdx.x * a.s_stride;
+    const long len = a.len;
+    const CoarseGeom g = coarse_geom(a);
+    const int fft_len = g.fft_len, mv_len = g.mv_len;
+    const double th = g.th;
     const int tid = threadIdx.x;
-    cplx* tw = (cplx*)smem;                              // 64 twiddles
-    double* sums = (double*)(tw + 64);                   // COARSE_CHUNK running sums
-    double* snr_s = sums + COARSE_CHUNK;                 // nwin SNRs
+    {
+        const uint4* src = (const uint4*)st_g;
+        uint4* dst = (uint4*)st;
+        for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
+    }
+    coarse_twiddles(tw, fft_len, tid, 256);
+    const bool bad = fft_len > 64 || fft_len < 2 || g.n_first > len;   // s(1:n_first): MATLAB index error
+    // padded copy S = [999 x mv_len | snr[0..nwin) | 0 x 64]: S[q] is the SNR evicted by window q
+    // (999 while the history still holds its seed, move_fft_snr_runtime_avg.m:11), S[mv_len+q] is
+    // window q's own SNR; every load of the unrolled recurrence below is unconditional.
+    if (!bad && a.mode != 2) {
+        const double* sg = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
+        for (long i = tid; i < mv_len + g.nwin + 64; i += 256)
+            snr_s[i] = i < mv_len ? 999.0 : (i < mv_len + g.nwin ? sg[i - mv_len] : 0.0);
+    }
+    __syncthreads();
     if (tid == 0) {
         st->n_coarse = 0;
         st->coarse_hit_flag = 0;
@@ -164,136 +217,140 @@ __global__ void __launch_bounds__(256) k_coarse(StreamState* __restrict__ sts, C
         st->mv_hit_idx = -1.0;
         st->mv_hit_snr = INFINITY;
         sh_hit = 0x7fffffff;
+        if (bad) set_status(st, 3, GSMCAL_E_INDEX);
     }
-    if (fft_len != 16 && fft_len >= 2 && fft_len <= 64)
-        for (int i = tid; i < fft_len; i += 256) {
-            double sn, cs;
-            sincospi(-2.0 * (double)i / (double)fft_len, &sn, &cs);
-            tw[i] = make_double2(cs, sn);
-        }
     __syncthreads();
-    if (fft_len > 64 || fft_len < 2 || n_first > len) {  // s(1:n_first) would be a MATLAB index error
-        if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
-        return;
-    }
-    double hit_avg_snr = a.avg_snr;
-    if (a.mode != 2) {
+    int n = 0;
+    if (!bad && a.mode != 2) {
         // ---- move_fft_snr_runtime_avg ----
-        const long nwin = n_first - (fft_len - 1);
+        const long nwin = g.nwin;
         const double dmv = (double)mv_len;
-        if (tid == 0) {
-            // :11-12 store = 999*ones(1,mv_len); sum_snr = sum(store): sequential sum of 999s
+        if (tid < 64) {
+            const int lane = tid;
+            // :11-12 store = 999*ones(1,mv_len); sum_snr = sum(store): sequential sum of 999s (wave-uniform)
             double sum_snr = 0.0;
             for (int i = 0; i < mv_len; ++i) sum_snr += 999.0;
-            sh_sum = sum_snr;
-        }
-        int hit = 0x7fffffff;
-        for (long c0 = 0; c0 < nwin; c0 += COARSE_CHUNK) {
-            const int cn = (int)(nwin - c0 < COARSE_CHUNK ? nwin - c0 : COARSE_CHUNK);
-            for (int j = tid; j < cn; j += 256) snr_s[c0 + j] = window_snr(s + c0 + j, fft_len, tw);   // (A)
-            __syncthreads();
-            if (tid == 0) {                                                                               // (B)
-                double sum_snr = sh_sum;
-                for (int j = 0; j < cn; ++j) {
-                    const long i = c0 + j;
-                    sums[j] = sum_snr;
-                    const double oldest = i >= mv_len ? snr_s[i - mv_len] : 999.0;
-                    sum_snr = sum_snr - oldest;                          // :37
-                    sum_snr = sum_snr + snr_s[i];                        // :38
+            for (int base = 0; base < (int)nwin; base += 64) {
+                const int i = base + lane;
+                const double nw = snr_s[mv_len + i];                  // (in-bounds by the zero suffix)
+                double mine = 0.0;
+                const double* So = snr_s + base;                     // evicted values
+                const double* Sn = snr_s + mv_len + base;            // new values
+#pragma unroll
+                for (int j0 = 0; j0 < 64; j0 += 8) {
+                    double o[8], v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {                    // wave-uniform (broadcast) LDS reads
+                        v[u] = Sn[j0 + u];
+                        o[u] = So[j0 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        mine = lane == j0 + u ? sum_snr : mine;      // the sum window j sees
+                        sum_snr = sum_snr - o[u];                    // :37
+                        sum_snr = sum_snr + v[u];                    // :38
+                    }
+                }                                                    // (updates past nwin are never used)
+                const double avg = mine / dmv;
+                const bool h = i < nwin && (nw - avg > th);          // :30-32 strict >
+                const unsigned long long m = __ballot(h);
+                if (m) {
+                    const int f = __ffsll((long long)m) - 1;
+                    if (lane == f) { sh_hit = (int)base + f; sh_avg = avg; }
+                    break;
                 }
-                sh_sum = sum_snr;
             }
-            __syncthreads();
-            int first = 0x7fffffff;                                                                       // (C)
-            for (int j = tid; j < cn; j += 256) {
-                const double pta = snr_s[c0 + j] - (sums[j] / dmv);      // :30
-                if (pta > th && j < first) first = j;                    // :32 strict >
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_down(first, off, 64);
-                first = o < first ? o : first;
-            }
-            if ((tid & 63) == 0 && first != 0x7fffffff) atomicMin(&sh_hit, (int)c0 + first);
-            __syncthreads();
-            hit = sh_hit;
-            if (hit != 0x7fffffff) break;                                // uniform
         }
+        __syncthreads();
+        const int hit = sh_hit;
         if (hit != 0x7fffffff && tid == 0) {
-            const double h_snr = snr_s[hit];
-            const double h_pta = h_snr - (sums[hit % COARSE_CHUNK] / dmv);
+            const double h_snr = snr_s[mv_len + hit];
+            const double h_pta = h_snr - sh_avg;
             st->coarse_hit_flag = 1;
             st->mv_hit_idx = (double)(hit + 1);
             st->mv_hit_snr = h_snr;
-            st->hit_avg_snr = h_snr - h_pta;                             // :48
+            st->hit_avg_snr = h_snr - h_pta;                         // :48
         }
         __syncthreads();
-        if (a.mode == 1) return;
-        if (hit == 0x7fffffff) {
-            if (tid == 0) set_status(st, 3, GSMCAL_S_NO_FCCH);
-            return;
+        if (a.mode == 0) {
+            if (hit == 0x7fffffff) {
+                if (tid == 0) set_status(st, 3, GSMCAL_S_NO_FCCH);
+            } else {
+                // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units) ----
+                const double hit_avg_snr = st->hit_avg_snr;
+                const int dec = a.decimation_ratio;
+                const long d0 = (long)round(12500.0 / (double)dec);     // :35 round() half away from zero
+                const long d1 = (long)round(13750.0 / (double)dec);     // :36
+                const int max_offset = 5;
+                const long limit = (len - (fft_len - 1)) - max_offset;
+                long cur = hit + 1;
+                n = 1;
+                if (tid == 0) {
+                    st->coarse_pos[0] = (double)((cur - 1) * dec + 1);  // :91
+                    st->coarse_snr[0] = st->mv_hit_snr;
+                }
+                const int nt = 2 * max_offset + 1;
+                double* hop = snr_s;                                     // the scan is over: reuse
+                while (n < MAXH) {
+                    const long nx0 = cur + d0, nx1 = cur + d1;
+                    if (nx0 > limit) break;                              // :49
+                    __syncthreads();
+                    if (tid < nt) hop[tid] = window_snr(s + (nx0 - max_offset - 1 + tid), fft_len, tw);
+                    else if (tid < 2 * nt && nx1 <= limit)
+                        hop[tid] = window_snr(s + (nx1 - max_offset - 1 + (tid - nt)), fft_len, tw);
+                    __syncthreads();
+                    int found = -1;
+                    long nxt = nx0;
+                    for (int i = 0; i < nt; ++i)                         // every thread scans: uniform result
+                        if (hop[i] - hit_avg_snr > th) { found = i; break; }
+                    if (found < 0) {
+                        if (nx1 > limit) break;                          // :67
+                        nxt = nx1;                                       // :65 across the idle frame
+                        for (int i = 0; i < nt; ++i)
+                            if (hop[nt + i] - hit_avg_snr > th) { found = nt + i; break; }
+                        if (found < 0) break;
+                    }
+                    const double fsnr = hop[found];
+                    cur = nxt - max_offset + (found >= nt ? found - nt : found);
+                    if (tid == 0) {
+                        st->coarse_pos[n] = (double)((cur - 1) * dec + 1);
+                        st->coarse_snr[n] = fsnr;
+                    }
+                    ++n;
+                }
+                if (tid == 0) st->n_coarse = n;
+            }
         }
-        hit_avg_snr = st->hit_avg_snr;
-    }
-    if (a.mode == 2) {
+    } else if (!bad) {
         // ---- specific_fft_snr_fix_avg stand-alone ----
         const long lo = a.t_lo, hi = a.t_hi;
-        if (hi < lo) return;
-        if (lo < 1 || hi + fft_len - 1 > len) {
-            if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
-            return;
-        }
-        const long cnt = hi - lo + 1;
-        for (long i = tid; i < cnt; i += 256) snr_s[i] = window_snr(s + (lo - 1 + i), fft_len, tw);
-        __syncthreads();
-        if (tid == 0) {
-            for (long i = 0; i < cnt; ++i)
-                if (snr_s[i] - hit_avg_snr > th) {
-                    st->coarse_hit_flag = 1;
-                    st->mv_hit_idx = (double)(lo + i);
-                    st->mv_hit_snr = snr_s[i];
-                    break;
+        if (hi >= lo) {
+            if (lo < 1 || hi + fft_len - 1 > len) {
+                if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
+            } else {
+                const long cnt = hi - lo + 1;
+                for (long i = tid; i < cnt; i += 256) snr_s[i] = window_snr(s + (lo - 1 + i), fft_len, tw);
+                __syncthreads();
+                if (tid == 0) {
+                    for (long i = 0; i < cnt; ++i)
+                        if (snr_s[i] - a.avg_snr > th) {
+                            st->coarse_hit_flag = 1;
+                            st->mv_hit_idx = (double)(lo + i);
+                            st->mv_hit_snr = snr_s[i];
+                            break;
+                        }
                 }
+            }
         }
-        return;
     }
-    // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units) ----
-    const int dec = a.decimation_ratio;
-    const long d0 = (long)round(12500.0 / (double)dec);     // :35 round() half away from zero
-    const long d1 = (long)round(13750.0 / (double)dec);     // :36
-    const int max_offset = 5;
-    const long limit = (len - (fft_len - 1)) - max_offset;
-    long cur = sh_hit + 1;
-    int n = 1;
-    if (tid == 0) {
-        st->coarse_pos[0] = (double)((cur - 1) * dec + 1);  // :91
-        st->coarse_snr[0] = st->mv_hit_snr;
+    __syncthreads();
+    if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0);
+    __syncthreads();
+    {
+        const uint4* src = (const uint4*)st;
+        uint4* dst = (uint4*)st_g;
+        for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
     }
-    const int nt = 2 * max_offset + 1;
-    double* hop = sums;                                      // reuse: nt SNRs per attempt
-    while (n < MAXH) {
-        long nxt = cur + d0;
-        if (nxt > limit) break;                              // :49
-        int found = -1;
-        double fsnr = 0.0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            __syncthreads();
-            if (tid < nt) hop[tid] = window_snr(s + (nxt - max_offset - 1 + tid), fft_len, tw);
-            __syncthreads();
-            for (int i = 0; i < nt; ++i)                     // every thread scans: uniform result
-                if (hop[i] - hit_avg_snr > th) { found = i; fsnr = hop[i]; break; }
-            if (found >= 0 || attempt == 1) break;
-            nxt = cur + d1;                                  // :65 across the idle frame
-            if (nxt > limit) break;                          // :67
-        }
-        if (found < 0) break;
-        cur = nxt - max_offset + found;
-        if (tid == 0) {
-            st->coarse_pos[n] = (double)((cur - 1) * dec + 1);
-            st->coarse_snr[n] = fsnr;
-        }
-        ++n;
-    }
-    if (tid == 0) st->n_coarse = n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,6 +363,44 @@ __global__ void __launch_bounds__(256) k_coarse(StreamState* __restrict__ sts, C
 //   MODE 1: X of the window's first nfft samples -> global x0[s][w][k]
 // grid (H, S), block 256.  LDS: x[nfft] | B[37][N2+1] | tw[nfft].
 // ------------------------------------------------------------------------------------------------
+// step 1 of the 37 x N2 split: B[k1][n2] = W_nfft^(n2*k1) * sum_n1 x[N2*n1+n2] * W_37^(n1*k1), W_37^m = tw[N2*m]
+__device__ __forceinline__ void fft37_step1(const cplx* xs, cplx* B, const cplx* tw, int nfft, int N2, int ldb, int tid) {
+    constexpr int N1 = 37;
+    for (int o = tid; o < nfft; o += 256) {
+        const int k1 = o / N2, n2 = o - k1 * N2;
+        double ar = 0.0, ai = 0.0;
+        int idx = 0;
+        const int stp = (N2 * k1) % nfft;
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const cplx v = xs[N2 * n1 + n2], t = tw[idx];
+            ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+            ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+            idx += stp;
+            if (idx >= nfft) idx -= nfft;
+        }
+        const cplx t = tw[(n2 * k1) % nfft];
+        B[k1 * ldb + n2] = make_double2(ar * t.x - ai * t.y, ar * t.y + ai * t.x);
+    }
+}
+
+// step 2 for one output bin k = k1 + 37*k2: X[k] = sum_n2 B[k1][n2] * W_N2^(n2*k2), W_N2^m = tw[37*m]
+__device__ __forceinline__ cplx fft37_step2_bin(const cplx* B, const cplx* tw, int nfft, int N2, int ldb, int k) {
+    constexpr int N1 = 37;
+    const int k2 = k / N1, k1 = k - k2 * N1;
+    double ar = 0.0, ai = 0.0;
+    int idx = 0;
+    const int stp = (N1 * k2) % nfft;
+    const cplx* row = B + k1 * ldb;
+    for (int n2 = 0; n2 < N2; ++n2) {
+        const cplx v = row[n2], t = tw[idx];
+        ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+        ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+        idx += stp;
+        if (idx >= nfft) idx -= nfft;
+    }
+    return make_double2(ar, ai);
+}
+
 __global__ void k_make_twiddles(cplx* tw, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -334,39 +429,13 @@ __global__ void __launch_bounds__(256) k_fft_burst(const StreamState* __restrict
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < nfft; i += 256) { xs[i] = x[i]; tw[i] = tw_g[i]; }
     __syncthreads();
-    // step 1: B[k1][n2] = W_nfft^(n2*k1) * sum_n1 x[N2*n1+n2] * W_37^(n1*k1),  W_37^m = tw[N2*m]
-    for (int o = tid; o < nfft; o += 256) {
-        const int k1 = o / N2, n2 = o - k1 * N2;
-        double ar = 0.0, ai = 0.0;
-        int idx = 0;
-        const int stp = (N2 * k1) % nfft;
-        for (int n1 = 0; n1 < N1; ++n1) {
-            const cplx v = xs[N2 * n1 + n2], t = tw[idx];
-            ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
-            ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-            idx += stp;
-            if (idx >= nfft) idx -= nfft;
-        }
-        const cplx t = tw[(n2 * k1) % nfft];
-        B[k1 * ldb + n2] = make_double2(ar * t.x - ai * t.y, ar * t.y + ai * t.x);
-    }
+    fft37_step1(xs, B, tw, nfft, N2, ldb, tid);
     __syncthreads();
-    // step 2: X[k1 + 37*k2] = sum_n2 B[k1][n2] * W_N2^(n2*k2),  W_N2^m = tw[37*m]
     double best = -1.0;
     int key = 0x7fffffff, kk = 0;
     for (int k = tid; k < nfft; k += 256) {
-        const int k2 = k / N1, k1 = k - k2 * N1;
-        double ar = 0.0, ai = 0.0;
-        int idx = 0;
-        const int stp = (N1 * k2) % nfft;
-        const cplx* row = B + k1 * ldb;
-        for (int n2 = 0; n2 < N2; ++n2) {
-            const cplx v = row[n2], t = tw[idx];
-            ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
-            ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-            idx += stp;
-            if (idx >= nfft) idx -= nfft;
-        }
+        const cplx X = fft37_step2_bin(B, tw, nfft, N2, ldb, k);
+        const double ar = X.x, ai = X.y;
         if (MODE == 1) {
             x0[((size_t)s * H + w) * nfft + k] = make_double2(ar, ai);
         } else {

@@ -8,6 +8,7 @@
 #pragma once
 #include "state.h"
 #include "kernels_frontend.h"
+#include "kernels_detect.h"
 
 #define GSM_SYMBOL_RATE ((1625.0 / 6.0) * 1e3)
 #define TWO_PI_D (2.0 * 3.14159265358979323846)
@@ -22,16 +23,21 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tone: grid (H, S), block 256.  win: bursts of nfft samples.  peaks: spectrum argmax partials.
+// k_tone: grid (H, S), block 256.  win: bursts of nfft samples.  peaks: spectrum argmax (one per burst).
 // Writes st->fo_burst[w] and (do_gate) st->snr_burst[w].
+// LDS: xs[nfft] | (gate) B[37][N2+1] | tw[nfft] | P[nfft].
+// The SNR gate needs only the bins [0,hnl) and [nfft-hnl,nfft): step 1 of the 37 x N2 FFT in full,
+// step 2 for those bins only.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, const cplx* __restrict__ win,
                                               long win_stream_stride, long win_stride, int nfft,
-                                              const PeakOut* __restrict__ peaks, int H, int NB,
-                                              int ov, int do_gate) {
+                                              const PeakOut* __restrict__ peaks, int H,
+                                              const cplx* __restrict__ tw_g, int ov, int do_gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N2 = nfft / 37, ldb = N2 + 1;
     cplx* xs = (cplx*)smem;            // nfft derotated samples
-    cplx* tw = xs + nfft;              // nfft twiddles exp(-2 pi i m / nfft) (gate only)
+    cplx* B = xs + nfft;               // 37 * ldb   (gate only)
+    cplx* tw = B + 37 * ldb;           // nfft twiddles exp(-2 pi i m / nfft) (gate only)
     double* P = (double*)(tw + nfft);  // nfft bin powers (only the gate's bins are filled)
     __shared__ double red[8];
     __shared__ double sh_phase;
@@ -40,7 +46,7 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
     if (w >= st->n_win) return;
     const int tid = threadIdx.x;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    const PeakOut pk = merge_peaks(peaks + ((size_t)s * H + w) * NB, NB);
+    const PeakOut pk = peaks[(size_t)s * H + w];
     const int max_idx = pk.tie + 1;                                    // 1-based index after fftshift
     const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
     // :151  int_phase_rotate = 2.*pi.*(max_idx - ((fft_len/2)+1))./fft_len
@@ -50,6 +56,7 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
         double sn, cs;
         sincos((double)n * ipr, &sn, &cs);
         xs[n] = cmul(x[n], make_double2(cs, -sn));
+        if (do_gate) tw[n] = tw_g[n];
     }
     __syncthreads();
     // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) )
@@ -86,25 +93,16 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
         sincos((double)n * phase, &sn, &cs);
         const cplx v = xs[n];                       // each n is owned by exactly one thread
         xs[n] = cmul(v, make_double2(cs, -sn));
-        sincospi(-2.0 * (double)n / (double)nfft, &sn, &cs);
-        tw[n] = make_double2(cs, sn);
     }
     __syncthreads();
+    fft37_step1(xs, B, tw, nfft, N2, ldb, tid);
+    __syncthreads();
     const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
-    // bins needed: [0, hnl) and [nfft-hnl, nfft)
-    const int nb = 2 * hnl;
+    const int nb = 2 * hnl;                         // bins needed: [0, hnl) and [nfft-hnl, nfft)
     for (int b = tid; b < nb; b += 256) {
         const int k = b < hnl ? b : nfft - nb + b;
-        double ar = 0.0, ai = 0.0;
-        int idx = 0;
-        for (int n = 0; n < nfft; ++n) {
-            const cplx v = xs[n], t = tw[idx];
-            ar += v.x * t.x - v.y * t.y;
-            ai += v.x * t.y + v.y * t.x;
-            idx += k;
-            if (idx >= nfft) idx -= nfft;
-        }
-        const double m = hypot(ar, ai);
+        const cplx X = fft37_step2_bin(B, tw, nfft, N2, ldb, k);
+        const double m = hypot(X.x, X.y);
         P[k] = m * m;
     }
     __syncthreads();
@@ -126,7 +124,7 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
 __global__ void __launch_bounds__(128) k_sch_corr(StreamState* __restrict__ sts, const cplx* __restrict__ win,
                                                   long win_stream_stride, long win_stride,
                                                   const cplx* __restrict__ ts, int len_ts, int nshift,
-                                                  int* __restrict__ edge_flags) {
+                                                  int unused_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx* xs = (cplx*)smem;                 // window
     cplx* tc = xs + (nshift - 1 + len_ts);  // conj(ts)
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(128) k_sch_corr(StreamState* __restrict__ sts,
         for (int o = 1; o < nshift; ++o)
             if (cv[o] > mx) { mx = cv[o]; mi = o; }
         st->sch_first[w] = (double)(st->win_start[w] + 1 + mi);   // sp + max_idx - 1
-        if (mi == 0 || mi == nshift - 1) atomicOr(&edge_flags[s], 1);   // :59
+        if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
     }
 }
 
@@ -171,10 +169,8 @@ __device__ __forceinline__ void fine_sentinel(StreamState* st) {
 }
 
 // FCCH_fine_correction.m:8-46 -- window list for the fine search (level `lvl`)
-__global__ void k_fine_setup(StreamState* sts, int S, int ov, int lvl) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl) {
+    (void)s;
     fine_sentinel(st);
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
     if (st->status < 0) return;
@@ -194,10 +190,8 @@ __global__ void k_fine_setup(StreamState* sts, int S, int ov, int lvl) {
 }
 
 // FCCH_fine_correction.m:52-137 -- positions, sampling error, new grid, burst windows at level lvl+1
-__global__ void k_fine_decide(StreamState* sts, int S, const PeakOut* peaks, int H, int NB, int ov, int lvl) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int H, int NB, int ov, int lvl) {
+    (void)s;
     if (st->status < 0 || st->stage_status[0] != 0) { st->n_win = 0; return; }
     const int last_idx = st->n_win;
     for (int w = 0; w < last_idx; ++w) {
@@ -285,10 +279,8 @@ __device__ __forceinline__ double carrier_from_bursts(StreamState* st, int nb, i
 }
 
 // FCCH_fine_correction.m:158-165,192-196
-__global__ void k_carrier_decide(StreamState* sts, int S, int ov, const double* carrier_freq, int lvl) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl) {
+    (void)s;
     const int nb = st->n_win;
     st->n_win = 0;
     if (nb == 0) return;
@@ -304,11 +296,9 @@ __global__ void k_carrier_decide(StreamState* sts, int S, int ov, const double* 
 }
 
 // SCH_corr_rate_correction.m:8-48 -- correlation windows at level lvl
-__global__ void k_sch_setup(StreamState* sts, int S, int ov, int len_ts, int lvl, int* edge_flags) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
-    edge_flags[s] = 0;
+__device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl) {
+    (void)s;
+    st->sch_edge = 0;
     st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0;
     st->sampling_ppm2 = INFINITY; st->r2_kind = 0;
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
@@ -329,15 +319,13 @@ __global__ void k_sch_setup(StreamState* sts, int S, int ov, int len_ts, int lvl
 }
 
 // SCH_corr_rate_correction.m:59-181
-__global__ void k_sch_decide(StreamState* sts, int S, int ov, int lvl, const int* edge_flags) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl) {
+    (void)s;
     const int num_sch = st->n_win;
     st->n_win = 0;
     if (st->status < 0 || st->stage_status[1] != 0) return;
     st->n_sch_first = num_sch;
-    if (edge_flags[s]) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63
+    if (st->sch_edge) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63
     if (num_sch < 5) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }          // :84
     const double frame_ov = 1250.0 * (double)ov, slot_ov = 156.25 * (double)ov;
     const double d_ov = 10.0 * frame_ov, d1_ov = 11.0 * frame_ov;
@@ -420,10 +408,8 @@ __global__ void k_sch_decide(StreamState* sts, int S, int ov, int lvl, const int
 }
 
 // carrier_correct_post_SCH.m:8-62 -- FCCH-row windows at level lvl
-__global__ void k_post_setup(StreamState* sts, int S, int ov, int lvl) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_post_setup(StreamState* st, int s, int ov, int lvl) {
+    (void)s;
     st->n_win = 0; st->carrier_ppm2 = INFINITY; st->r3_kind = 0;
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
     if (st->status < 0) return;
@@ -446,10 +432,8 @@ __global__ void k_post_setup(StreamState* sts, int S, int ov, int lvl) {
 }
 
 // carrier_correct_post_SCH.m:75-83
-__global__ void k_post_decide(StreamState* sts, int S, int ov, const double* carrier_freq, int lvl) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    StreamState* st = sts + s;
+__device__ void d_post_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl) {
+    (void)s;
     const int nb = st->n_win;
     st->n_win = 0;
     if (nb == 0) return;
@@ -464,10 +448,7 @@ __host__ __device__ inline double total_ppm(double a, double b) {
 }
 
 // gsm_sync_demod.m:123-124 + table row
-__global__ void k_totals(const StreamState* sts, int S, double* table, double* pos_info_out, long* r_len_out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const StreamState* st = sts + s;
+__device__ void d_totals(const StreamState* st, int s, double* table, double* pos_info_out, long* r_len_out) {
     double* row = table + (size_t)s * GSMCAL_TABLE_COLS;
     row[GSMCAL_T_SAMPLING_PPM_FCCH] = st->sampling_ppm1;
     row[GSMCAL_T_SAMPLING_PPM_SCH] = st->sampling_ppm2;
@@ -488,11 +469,8 @@ __global__ void k_totals(const StreamState* sts, int S, double* table, double* p
 }
 
 // multi_rtl_sdr_gsm_FCCH_scanner.m:168-185 acceptance -> (snr, num_hit) per capture
-__global__ void k_scan_accept(const StreamState* sts, int S, double* snr_numhit, double* positions,
+__device__ void d_scan_accept(const StreamState* st, int s, double* snr_numhit, double* positions,
                               double* pos_snr, int* counts) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const StreamState* st = sts + s;
     const int n = st->n_coarse;
     double snr = 0.0, num_hit = 0.0;
     if (n >= 3) {
@@ -516,4 +494,58 @@ __global__ void k_scan_accept(const StreamState* sts, int S, double* snr_numhit,
             positions[(size_t)s * MAXH + i] = i < n ? st->coarse_pos[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
             if (pos_snr) pos_snr[(size_t)s * MAXH + i] = i < n ? st->coarse_snr[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers for the decision steps: grid S, block 64.  The stream's state is copied into LDS with
+// coalesced 16-byte accesses, lane 0 runs the (serial, branchy) reference logic on the LDS copy, and
+// the state is copied back -- the logic is a chain of dependent loads/stores that would otherwise
+// each pay a global-memory round trip.
+// ------------------------------------------------------------------------------------------------
+struct StateLds {
+    __device__ static void load(StreamState* sh, const StreamState* g, int lane) {
+        const uint4* src = (const uint4*)g;
+        uint4* dst = (uint4*)sh;
+        for (int i = lane; i < (int)(sizeof(StreamState) / 16); i += 64) dst[i] = src[i];
+    }
+    __device__ static void store(StreamState* g, const StreamState* sh, int lane) {
+        const uint4* src = (const uint4*)sh;
+        uint4* dst = (uint4*)g;
+        for (int i = lane; i < (int)(sizeof(StreamState) / 16); i += 64) dst[i] = src[i];
+    }
+};
+
+struct StepArgs {
+    int ov, lvl, len_ts, H, NB;
+    const PeakOut* peaks;
+    const double* carrier_freq;
+    double* table; double* pos_info_out; long* r_len_out;
+    double* snr_numhit; double* positions; double* pos_snr; int* counts;
+};
+
+enum { STEP_FINE_SETUP = 1, STEP_FINE_DECIDE = 2, STEP_CARRIER_DECIDE = 4, STEP_SCH_SETUP = 8, STEP_SCH_DECIDE = 16,
+       STEP_POST_SETUP = 32, STEP_POST_DECIDE = 64, STEP_TOTALS = 128, STEP_SCAN_ACCEPT = 256 };
+
+// `steps` is a bit set executed in the order of the enum; lvl_a / lvl_b: input level of the first /
+// second step of a merged pair (e.g. carrier_decide works on the fine stage's level, sch_setup on the
+// SCH stage's input level).
+template <int STEPS>
+__global__ void __launch_bounds__(64) k_step(StreamState* __restrict__ sts, StepArgs a, int lvl_a, int lvl_b) {
+    __shared__ StreamState sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    StateLds::load(&sh, sts + s, lane);
+    __syncthreads();
+    if (lane == 0) {
+        if (STEPS & STEP_FINE_SETUP) d_fine_setup(&sh, s, a.ov, lvl_a);
+        if (STEPS & STEP_FINE_DECIDE) d_fine_decide(&sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);
+        if (STEPS & STEP_CARRIER_DECIDE) d_carrier_decide(&sh, s, a.ov, a.carrier_freq, lvl_a);
+        if (STEPS & STEP_SCH_SETUP) d_sch_setup(&sh, s, a.ov, a.len_ts, lvl_b);
+        if (STEPS & STEP_SCH_DECIDE) d_sch_decide(&sh, s, a.ov, lvl_a);
+        if (STEPS & STEP_POST_SETUP) d_post_setup(&sh, s, a.ov, lvl_b);
+        if (STEPS & STEP_POST_DECIDE) d_post_decide(&sh, s, a.ov, a.carrier_freq, lvl_a);
+        if (STEPS & STEP_TOTALS) d_totals(&sh, s, a.table, a.pos_info_out, a.r_len_out);
+        if (STEPS & STEP_SCAN_ACCEPT) d_scan_accept(&sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts);
+    }
+    __syncthreads();
+    if (!(STEPS == STEP_TOTALS || STEPS == STEP_SCAN_ACCEPT)) StateLds::store(sts + s, &sh, lane);
 }

@@ -23,6 +23,11 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 // [0, n) read as 0 (filter()'s zero initial state is applied by the callers through g < 0 tests).
 // r_s must hold span + 16 ushorts and be 16-byte aligned.
 // ------------------------------------------------------------------------------------------------
+// PAD: insert 8 ushorts (16 B) after every 64 samples so that lanes whose samples are 64 apart (the
+// decimate-by-64 FIR) do not all hit the same LDS bank; use lds_pad() to index.
+__device__ __forceinline__ int lds_pad(int rel) { return rel + ((rel >> 6) << 3); }
+
+template <bool PAD = false>
 __device__ __forceinline__ long stage_raw(unsigned short* r_s, const unsigned short* base, long n, long first,
                                           int span, int tid, int nthreads) {
     const long ao = (long)(((uintptr_t)base >> 1) & 7);          // samples past a 16-byte boundary at g = 0
@@ -42,7 +47,7 @@ __device__ __forceinline__ long stage_raw(unsigned short* r_s, const unsigned sh
             v.x = t[0] | ((unsigned)t[1] << 16); v.y = t[2] | ((unsigned)t[3] << 16);
             v.z = t[4] | ((unsigned)t[5] << 16); v.w = t[6] | ((unsigned)t[7] << 16);
         }
-        *(uint4*)(r_s + 8 * c) = v;
+        *(uint4*)(r_s + (PAD ? lds_pad(8 * c) : 8 * c)) = v;
     }
     return first_al;
 }
@@ -102,12 +107,19 @@ __global__ void __launch_bounds__(256) k_dc_sum(const uint8_t* __restrict__ raw,
 }
 
 // raw2iq.m:8  mean = sum(c,1)./size(c,1) : exact integer sums divided once in double
-__global__ void k_finish_mean(StreamState* st, int S) {
+// (the state array was zeroed by hipMemsetAsync; this also writes the non-zero defaults = the
+// sentinels the reference functions start from)
+__global__ void k_finish_mean(StreamState* st, int S, long n0) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    const double n = (double)st[s].n0;
+    const double n = (double)n0;
+    st[s].n0 = n0;
     st[s].mean_re = (double)st[s].sum_i / n;
     st[s].mean_im = (double)st[s].sum_q / n;
+    st[s].hit_avg_snr = INFINITY;
+    st[s].sampling_ppm1 = INFINITY; st[s].carrier_ppm1 = INFINITY;
+    st[s].sampling_ppm2 = INFINITY; st[s].carrier_ppm2 = INFINITY;
+    st[s].fcch_is_sentinel = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,7 +163,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
     const long last = (j0 + jn - 1) * decim;                // last sample index needed
     const int span = (int)(last - first + 1);
     for (int i = threadIdx.x; i < ntaps; i += 256) c_s[i] = coef[i];
-    const long first_al = stage_raw(r_s, base, n, first, span, threadIdx.x, 256);
+    const long first_al = stage_raw<true>(r_s, base, n, first, span, threadIdx.x, 256);
     __syncthreads();
     const int t = threadIdx.x;
     if (t >= jn) return;
@@ -161,7 +173,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
     for (int k = ntaps - 1; k >= 0; --k) {
         const long g = i_out - k;
         if (g < 0) continue;                                 // zero initial state
-        const unsigned short v = r_s[g - first_al];
+        const unsigned short v = r_s[lds_pad((int)(g - first_al))];
         const double c = c_s[k];
         ar = fma(c, (double)(v & 0xFF) - mr, ar);
         ai = fma(c, (double)(v >> 8) - mi, ai);
@@ -209,13 +221,20 @@ __device__ __forceinline__ long level_len(const StreamState* st, int level) {
     return level == 0 ? st->n0 : st->op[level].n;
 }
 
+// LDS position of staged input sample p: one 16-byte pad after every 4 samples, so that lanes reading
+// samples 4 apart (the 4-outputs-per-lane FIR below) hit distinct banks with ds_read_b128.
+__device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
+
 __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int bufn = a.len + 8;
+    // LDS carve (host: gather_lds): buf0 | buf1 | coef | raw ushorts | xs (padded complex input)
+    const int bufn = a.level >= 1 ? a.len + 8 : 0;
     cplx* buf0 = (cplx*)smem;
     cplx* buf1 = buf0 + bufn;
-    double* c_s = (double*)(buf1 + bufn);
+    double* c_s = (double*)(buf1 + (a.level >= 2 ? bufn : 0));
     unsigned short* r_s = (unsigned short*)(c_s + ((a.ntaps + 1) & ~1));
+    const int span_max = a.len + 8 + a.ntaps + 24;
+    cplx* xs = (cplx*)(r_s + ((span_max + 7) & ~7));
     const int s = blockIdx.y;
     const StreamState* st = sts + s;
     const int level = a.level;
@@ -253,34 +272,57 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
     const long lo0 = lo[0], hi0 = hi[0];
     const int cnt0 = (int)(hi0 - lo0 + 1);
     cplx* out0 = (level == 0) ? dst : buf0;
+    const int tid = threadIdx.x;
     if (a.src_kind == SRC_ARR) {
         const cplx* x = a.arr + (size_t)s * a.arr_stride;
         const long n0 = st->n0;
-        for (int i = threadIdx.x; i < cnt0; i += 256) {
+        for (int i = tid; i < cnt0; i += 256) {
             const long g = lo0 + i;
             out0[i] = (g >= 0 && g < n0) ? x[g] : make_double2(0.0, 0.0);
         }
     } else {
         const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
         const long n0 = st->n0;
-        const long first = lo0 - (a.ntaps - 1);
-        const int span = cnt0 + a.ntaps - 1;
-        for (int i = threadIdx.x; i < a.ntaps; i += 256) c_s[i] = a.coef[i];
-        const long first_al = stage_raw(r_s, base, n0, first, span, threadIdx.x, 256);
+        const int ntp = a.ntaps;
+        const long first = lo0 - (ntp - 1);
+        const int span = cnt0 + ntp - 1;
+        for (int i = tid; i < ntp; i += 256) c_s[i] = a.coef[i];
+        const long first_al = stage_raw(r_s, base, n0, first, span, tid, 256);
         __syncthreads();
+        // raw2iq.m:6-8 on the staged span: (I - mean) + 1i (Q - mean); zero before the stream starts
+        // (filter()'s zero initial state) and past its end
         const double mr = st->mean_re, mi = st->mean_im;
-        for (int i = threadIdx.x; i < cnt0; i += 256) {
-            const long g_out = lo0 + i;
-            double ar = 0.0, ai = 0.0;
-            for (int k = a.ntaps - 1; k >= 0; --k) {
-                const long g = g_out - k;
-                if (g < 0 || g >= n0) continue;  // zero initial state
-                const unsigned short v = r_s[g - first_al];
-                const double c = c_s[k];
-                ar = fma(c, (double)(v & 0xFF) - mr, ar);
-                ai = fma(c, (double)(v >> 8) - mi, ai);
+        const int off = (int)(first - first_al);
+        for (int i = tid; i < span + 8; i += 256) {
+            const long g = first + i;
+            cplx v = make_double2(0.0, 0.0);
+            if (i < span && g >= 0 && g < n0) {
+                const unsigned short q = r_s[off + i];
+                v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
             }
-            out0[i] = make_double2(ar, ai);
+            xs[xs_pad(i)] = v;
+        }
+        __syncthreads();
+        // filter(coef,1,.) : y[i] = sum_k coef[k] x[i-k], accumulated oldest tap first (transposed
+        // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
+        for (int i0 = 4 * tid; i0 < cnt0; i0 += 1024) {
+            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
+            cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
+            int p = i0 + 3;
+            for (int k = ntp - 1; k >= 0; --k) {
+                const double c = c_s[k];
+                ar0 = fma(c, w0.x, ar0); ai0 = fma(c, w0.y, ai0);
+                ar1 = fma(c, w1.x, ar1); ai1 = fma(c, w1.y, ai1);
+                ar2 = fma(c, w2.x, ar2); ai2 = fma(c, w2.y, ai2);
+                ar3 = fma(c, w3.x, ar3); ai3 = fma(c, w3.y, ai3);
+                w0 = w1; w1 = w2; w2 = w3;
+                ++p;
+                w3 = xs[xs_pad(p)];
+            }
+            out0[i0] = make_double2(ar0, ai0);
+            if (i0 + 1 < cnt0) out0[i0 + 1] = make_double2(ar1, ai1);
+            if (i0 + 2 < cnt0) out0[i0 + 2] = make_double2(ar2, ai2);
+            if (i0 + 3 < cnt0) out0[i0 + 3] = make_double2(ar3, ai3);
         }
     }
     // ---- levels 1..level ----

@@ -30,7 +30,7 @@ struct LevelOp {
     long n;        // length of this level's stream
 };
 
-struct StreamState {
+struct alignas(16) StreamState {
     // ---- level chain ----
     long n0;                 // length of level 0
     unsigned long long sum_i, sum_q;  // integer byte sums (raw sources)
@@ -57,6 +57,7 @@ struct StreamState {
     int r1_kind;             // what FCCH_fine_correction returns as r: 0 = -1, 1 = s, 2 = lerp only, 3 = lerp+mix
     // ---- SCH ----
     int n_sch_first;
+    int sch_edge;            // an SCH correlation peak sat on the edge of its search window (:59)
     double sch_first[MAXH];
     int n_sch;
     double sch_pos[MAXH];
