@@ -93,6 +93,9 @@ int gsmcal_memcpy_d2h(gsmcal_ctx* ctx, void* dst, const void* src, size_t bytes)
  * with events (serialises nothing, adds two event records per launch).  Stats accumulate until reset. */
 int gsmcal_profile_enable(gsmcal_ctx* ctx, int enable);
 int gsmcal_profile_reset(gsmcal_ctx* ctx);
+/* Restrict the bracketing to kernels whose name contains `substr` (NULL or "" = every kernel), so a
+ * timed region can carry events for one kernel only. */
+int gsmcal_profile_filter(gsmcal_ctx* ctx, const char* substr);
 /* Returns the number of distinct kernels seen; fills up to `cap` entries (name pointers stay valid
  * for the life of the library). total_ms[i] is the summed duration, launches[i] the launch count. */
 int gsmcal_profile_get(gsmcal_ctx* ctx, int cap, const char** names, double* total_ms, long* launches);

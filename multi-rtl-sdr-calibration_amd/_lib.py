@@ -31,6 +31,7 @@ SIGNATURES = {
     "gsmcal_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "gsmcal_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmcal_profile_reset": (C.c_int, [C.c_void_p]),
+    "gsmcal_profile_filter": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gsmcal_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), c_double_p, c_long_p]),
     "gsmcal_raw2iq": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p]),
     "gsmcal_raw2iq_u8": (C.c_int, [C.c_void_p, c_u8_p, C.c_long, C.c_int, c_double_p]),

@@ -89,6 +89,9 @@ class Context:
     def profile_enable(self, on=True):
         self.check(self.lib.gsmcal_profile_enable(self.h, 1 if on else 0), "gsmcal_profile_enable")
 
+    def profile_filter(self, substr=None):
+        self.check(self.lib.gsmcal_profile_filter(self.h, substr.encode() if substr else None), "gsmcal_profile_filter")
+
     def profile_reset(self):
         self.check(self.lib.gsmcal_profile_reset(self.h), "gsmcal_profile_reset")
 

@@ -48,6 +48,7 @@ struct gsmcal_ctx {
     int last_S = 0;
     // profiling
     bool prof = false;
+    std::string prof_filter;
     std::vector<std::string> prof_names;
     std::vector<double> prof_ms;
     std::vector<long> prof_n;
@@ -127,6 +128,7 @@ struct ProfScope {
     ProfRec r;
     bool on;
     ProfScope(gsmcal_ctx* ctx, const char* name) : c(ctx), on(ctx->prof) {
+        if (on && !c->prof_filter.empty() && !strstr(name, c->prof_filter.c_str())) on = false;
         if (on) {
             r.name_id = prof_id(c, name);
             r.e0 = get_event(c);
@@ -208,8 +210,8 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
     return 0;
 }
 
-size_t fft_lds(const Geom& g) {
-    return ((size_t)2 * g.nfft + (size_t)37 * (g.nfft / 37 + 1)) * sizeof(cplx);
+size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
+    return ((size_t)g.nfft + (size_t)37 * (g.nfft / 37 + 1) + 40 + g.nfft / 37) * sizeof(cplx);
 }
 
 StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
@@ -237,7 +239,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
-    LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+    LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->x0.p, H);
     LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1) * sizeof(cplx),
            (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->x0.p,
@@ -245,7 +247,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1
     RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
     const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
@@ -269,8 +271,8 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     RET_IF(launch_gather(c, S, src, lvl, wl, false, H, win, sstride, wstride));
-    const size_t lds = (size_t)(wl + len_ts) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
-    LAUNCH(c, k_sch_corr, dim3(H, S), dim3(128), lds, st, (const cplx*)win, sstride, wstride,
+    const size_t lds = (size_t)(wl + len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+    LAUNCH(c, k_sch_corr, dim3(H, S), dim3(512), lds, st, (const cplx*)win, sstride, wstride,
            (const cplx*)c->ts.p, len_ts, g.sch_nshift, 0);
     if (next_post_lvl >= 0)
         LAUNCH(c, k_step<STEP_SCH_DECIDE | STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_post_lvl);
@@ -295,7 +297,7 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(256), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
     const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
     LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
@@ -507,6 +509,11 @@ int gsmcal_profile_enable(gsmcal_ctx* c, int enable) {
     if (!c) return GSMCAL_E_ARG;
     RET_IF(prof_flush(c));
     c->prof = enable != 0;
+    return 0;
+}
+int gsmcal_profile_filter(gsmcal_ctx* c, const char* substr) {
+    if (!c) return GSMCAL_E_ARG;
+    c->prof_filter = substr ? substr : "";
     return 0;
 }
 int gsmcal_profile_reset(gsmcal_ctx* c) {

@@ -361,42 +361,56 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
 // and to start the sliding DFT of the fine search at its first window.
 //   MODE 0: argmax of |X|^2 in fftshift order -> PeakOut (one per window)
 //   MODE 1: X of the window's first nfft samples -> global x0[s][w][k]
-// grid (H, S), block 256.  LDS: x[nfft] | B[37][N2+1] | tw[nfft].
+// grid (H, S), block 512.  LDS: x[nfft] | B[37][N2+1] | w37 | wN2.
 // ------------------------------------------------------------------------------------------------
-// step 1 of the 37 x N2 split: B[k1][n2] = W_nfft^(n2*k1) * sum_n1 x[N2*n1+n2] * W_37^(n1*k1), W_37^m = tw[N2*m]
-__device__ __forceinline__ void fft37_step1(const cplx* xs, cplx* B, const cplx* tw, int nfft, int N2, int ldb, int tid) {
-    constexpr int N1 = 37;
-    for (int o = tid; o < nfft; o += 256) {
+// ---- 37 x N2 Cooley-Tukey building blocks (N2 = 4*ov; 32 for the reference's 8x oversampling) ----
+// tables in LDS: w37[m] = exp(-2 pi i m/37), wN2[m] = exp(-2 pi i m/N2); the inter-stage twiddle
+// exp(-2 pi i n2 k1 / nfft) comes from the global table tw_g (one read per output).
+__device__ __forceinline__ void fft37_tables(cplx* w37, cplx* wN2, int N2, int tid) {
+    if (tid < 37) {
+        double sn, cs;
+        sincospi(-2.0 * (double)tid / 37.0, &sn, &cs);
+        w37[tid] = make_double2(cs, sn);
+    } else if (tid >= 64 && tid < 64 + N2) {
+        double sn, cs;
+        sincospi(-2.0 * (double)(tid - 64) / (double)N2, &sn, &cs);
+        wN2[tid - 64] = make_double2(cs, sn);
+    }
+}
+
+// step 1: B[k1][n2] = W_nfft^(n2*k1) * sum_n1 x[N2*n1+n2] * W_37^(n1*k1)
+__device__ __forceinline__ void fft37_step1(const cplx* xs, cplx* B, const cplx* w37, const cplx* __restrict__ tw_g,
+                                            int nfft, int N2, int ldb, int tid, int nthreads) {
+    for (int o = tid; o < nfft; o += nthreads) {
         const int k1 = o / N2, n2 = o - k1 * N2;
         double ar = 0.0, ai = 0.0;
         int idx = 0;
-        const int stp = (N2 * k1) % nfft;
-        for (int n1 = 0; n1 < N1; ++n1) {
-            const cplx v = xs[N2 * n1 + n2], t = tw[idx];
+#pragma unroll
+        for (int n1 = 0; n1 < 37; ++n1) {
+            const cplx v = xs[N2 * n1 + n2], t = w37[idx];
             ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
             ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-            idx += stp;
-            if (idx >= nfft) idx -= nfft;
+            idx += k1;
+            idx = idx >= 37 ? idx - 37 : idx;
         }
-        const cplx t = tw[(n2 * k1) % nfft];
+        const cplx t = tw_g[n2 * k1];                   // n2*k1 < N2*37 = nfft
         B[k1 * ldb + n2] = make_double2(ar * t.x - ai * t.y, ar * t.y + ai * t.x);
     }
 }
 
-// step 2 for one output bin k = k1 + 37*k2: X[k] = sum_n2 B[k1][n2] * W_N2^(n2*k2), W_N2^m = tw[37*m]
-__device__ __forceinline__ cplx fft37_step2_bin(const cplx* B, const cplx* tw, int nfft, int N2, int ldb, int k) {
-    constexpr int N1 = 37;
-    const int k2 = k / N1, k1 = k - k2 * N1;
+// step 2 for one output bin k = k1 + 37*k2: X[k] = sum_n2 B[k1][n2] * W_N2^(n2*k2)
+__device__ __forceinline__ cplx fft37_step2_bin(const cplx* B, const cplx* wN2, int N2, int ldb, int k) {
+    const int k2 = k / 37, k1 = k - k2 * 37;
     double ar = 0.0, ai = 0.0;
     int idx = 0;
-    const int stp = (N1 * k2) % nfft;
     const cplx* row = B + k1 * ldb;
+#pragma unroll 8
     for (int n2 = 0; n2 < N2; ++n2) {
-        const cplx v = row[n2], t = tw[idx];
+        const cplx v = row[n2], t = wN2[idx];
         ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
         ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-        idx += stp;
-        if (idx >= nfft) idx -= nfft;
+        idx += k2;
+        idx = idx >= N2 ? idx - N2 : idx;
     }
     return make_double2(ar, ai);
 }
@@ -409,32 +423,35 @@ __global__ void k_make_twiddles(cplx* tw, int n) {
     tw[i] = make_double2(cs, sn);
 }
 
+#define FFT_THREADS 512
 template <int MODE>
-__global__ void __launch_bounds__(256) k_fft_burst(const StreamState* __restrict__ sts, const cplx* __restrict__ win,
-                                                   long win_stream_stride, long win_stride, int nfft,
-                                                   const cplx* __restrict__ tw_g, PeakOut* __restrict__ peaks,
-                                                   cplx* __restrict__ x0, int H) {
+__global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __restrict__ sts,
+                                                           const cplx* __restrict__ win, long win_stream_stride,
+                                                           long win_stride, int nfft,
+                                                           const cplx* __restrict__ tw_g, PeakOut* __restrict__ peaks,
+                                                           cplx* __restrict__ x0, int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int N1 = 37;
-    const int N2 = nfft / N1;
+    const int N2 = nfft / 37;
     const int ldb = N2 + 1;                     // padded row: conflict-free column reads in step 2
     cplx* xs = (cplx*)smem;                     // nfft
-    cplx* B = xs + nfft;                        // N1 * ldb
-    cplx* tw = B + N1 * ldb;                    // nfft
-    __shared__ double red_p[4];
-    __shared__ int red_t[4], red_k[4];
+    cplx* B = xs + nfft;                        // 37 * ldb
+    cplx* w37 = B + 37 * ldb;                   // 37 (+3 pad)
+    cplx* wN2 = w37 + 40;                       // N2
+    __shared__ double red_p[FFT_THREADS / 64];
+    __shared__ int red_t[FFT_THREADS / 64], red_k[FFT_THREADS / 64];
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    for (int i = tid; i < nfft; i += 256) { xs[i] = x[i]; tw[i] = tw_g[i]; }
+    for (int i = tid; i < nfft; i += FFT_THREADS) xs[i] = x[i];
+    fft37_tables(w37, wN2, N2, tid);
     __syncthreads();
-    fft37_step1(xs, B, tw, nfft, N2, ldb, tid);
+    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, FFT_THREADS);
     __syncthreads();
     double best = -1.0;
     int key = 0x7fffffff, kk = 0;
-    for (int k = tid; k < nfft; k += 256) {
-        const cplx X = fft37_step2_bin(B, tw, nfft, N2, ldb, k);
+    for (int k = tid; k < nfft; k += FFT_THREADS) {
+        const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
         const double ar = X.x, ai = X.y;
         if (MODE == 1) {
             x0[((size_t)s * H + w) * nfft + k] = make_double2(ar, ai);
@@ -455,7 +472,7 @@ __global__ void __launch_bounds__(256) k_fft_burst(const StreamState* __restrict
     if ((tid & 63) == 0) { red_p[wv] = best; red_t[wv] = key; red_k[wv] = kk; }
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < 4; ++i)
+        for (int i = 1; i < FFT_THREADS / 64; ++i)
             if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; kk = red_k[i]; }
         PeakOut o; o.p = best; o.tie = key; o.k = kk;
         peaks[(size_t)s * H + w] = o;

@@ -25,7 +25,7 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 // ------------------------------------------------------------------------------------------------
 // k_tone: grid (H, S), block 256.  win: bursts of nfft samples.  peaks: spectrum argmax (one per burst).
 // Writes st->fo_burst[w] and (do_gate) st->snr_burst[w].
-// LDS: xs[nfft] | (gate) B[37][N2+1] | tw[nfft] | P[nfft].
+// LDS: xs[nfft] | (gate) B[37][N2+1] | w37 | wN2 | P[nfft].
 // The SNR gate needs only the bins [0,hnl) and [nfft-hnl,nfft): step 1 of the 37 x N2 FFT in full,
 // step 2 for those bins only.
 // ------------------------------------------------------------------------------------------------
@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
     const int N2 = nfft / 37, ldb = N2 + 1;
     cplx* xs = (cplx*)smem;            // nfft derotated samples
     cplx* B = xs + nfft;               // 37 * ldb   (gate only)
-    cplx* tw = B + 37 * ldb;           // nfft twiddles exp(-2 pi i m / nfft) (gate only)
-    double* P = (double*)(tw + nfft);  // nfft bin powers (only the gate's bins are filled)
+    cplx* w37 = B + 37 * ldb;          // 37 (+3 pad)
+    cplx* wN2 = w37 + 40;              // N2
+    double* P = (double*)(wN2 + N2);   // nfft bin powers (only the gate's bins are filled)
     __shared__ double red[8];
     __shared__ double sh_phase;
     const int s = blockIdx.y, w = blockIdx.x;
@@ -56,8 +57,8 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
         double sn, cs;
         sincos((double)n * ipr, &sn, &cs);
         xs[n] = cmul(x[n], make_double2(cs, -sn));
-        if (do_gate) tw[n] = tw_g[n];
     }
+    if (do_gate) fft37_tables(w37, wN2, N2, tid);
     __syncthreads();
     // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) )
     double sr = 0.0, si = 0.0;
@@ -95,13 +96,13 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
         xs[n] = cmul(v, make_double2(cs, -sn));
     }
     __syncthreads();
-    fft37_step1(xs, B, tw, nfft, N2, ldb, tid);
+    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, 256);
     __syncthreads();
     const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
     const int nb = 2 * hnl;                         // bins needed: [0, hnl) and [nfft-hnl, nfft)
     for (int b = tid; b < nb; b += 256) {
         const int k = b < hnl ? b : nfft - nb + b;
-        const cplx X = fft37_step2_bin(B, tw, nfft, N2, ldb, k);
+        const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
         const double m = hypot(X.x, X.y);
         P[k] = m * m;
     }
@@ -118,33 +119,45 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sch_corr: grid (H, S), block 128.  window length nshift-1+len_ts; ts = sch_training_sequence.
-// Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; edge peaks flagged in *edge_flags.
+// k_sch_corr: grid (H, S), block 512.  window length nshift-1+len_ts; ts = sch_training_sequence.
+// Each of the nshift offsets is summed by 4 lanes (quarters of the template) and combined.
+// Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_sch_corr(StreamState* __restrict__ sts, const cplx* __restrict__ win,
+#define SCH_PARTS 4
+__global__ void __launch_bounds__(512) k_sch_corr(StreamState* __restrict__ sts, const cplx* __restrict__ win,
                                                   long win_stream_stride, long win_stride,
-                                                  const cplx* __restrict__ ts, int len_ts, int nshift,
-                                                  int unused_) {
+                                                  const cplx* __restrict__ ts, int len_ts, int nshift, int unused_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx* xs = (cplx*)smem;                 // window
     cplx* tc = xs + (nshift - 1 + len_ts);  // conj(ts)
-    double* cv = (double*)(tc + len_ts);    // nshift correlation powers
+    cplx* part = tc + len_ts;               // nshift * SCH_PARTS partial sums
+    double* cv = (double*)(part + nshift * SCH_PARTS);   // nshift correlation powers
     const int s = blockIdx.y, w = blockIdx.x;
     StreamState* st = sts + s;
     if (w >= st->n_win) return;
     const int tid = threadIdx.x;
     const int wl = nshift - 1 + len_ts;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    for (int i = tid; i < wl; i += 128) xs[i] = x[i];
-    for (int i = tid; i < len_ts; i += 128) tc[i] = make_double2(ts[i].x, -ts[i].y);
+    for (int i = tid; i < wl; i += 512) xs[i] = x[i];
+    for (int i = tid; i < len_ts; i += 512) tc[i] = make_double2(ts[i].x, -ts[i].y);
     __syncthreads();
-    for (int o = tid; o < nshift; o += 128) {
+    const int seg = (len_ts + SCH_PARTS - 1) / SCH_PARTS;
+    for (int t = tid; t < nshift * SCH_PARTS; t += 512) {
+        const int o = t % nshift, q = t / nshift;   // consecutive lanes: consecutive offsets (conflict-free reads)
+        const int n0 = q * seg, n1 = n0 + seg < len_ts ? n0 + seg : len_ts;
         double ar = 0.0, ai = 0.0;
-        for (int n = 0; n < len_ts; ++n) {
+#pragma unroll 8
+        for (int n = n0; n < n1; ++n) {
             const cplx c = tc[n], v = xs[o + n];
-            ar += c.x * v.x - c.y * v.y;
-            ai += c.x * v.y + c.y * v.x;
+            ar = fma(c.x, v.x, fma(-c.y, v.y, ar));
+            ai = fma(c.x, v.y, fma(c.y, v.x, ai));
         }
+        part[q * nshift + o] = make_double2(ar, ai);
+    }
+    __syncthreads();
+    for (int o = tid; o < nshift; o += 512) {
+        double ar = 0.0, ai = 0.0;
+        for (int q = 0; q < SCH_PARTS; ++q) { ar += part[q * nshift + o].x; ai += part[q * nshift + o].y; }
         const double m = hypot(ar, ai);
         cv[o] = m * m;                      // :53 abs(...).^2
     }
@@ -157,6 +170,7 @@ __global__ void __launch_bounds__(128) k_sch_corr(StreamState* __restrict__ sts,
         st->sch_first[w] = (double)(st->win_start[w] + 1 + mi);   // sp + max_idx - 1
         if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
     }
+    (void)unused_;
 }
 
 // ------------------------------------------------------------------------------------------------
