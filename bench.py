@@ -91,7 +91,10 @@ def main():
     r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if args.mode == "stream" else None
     gathered = torch.zeros((world * D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) if world > 1 else None
 
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated (non-default) stream: the library forks its internal lanes off this stream, and torch's
+    # collectives are enqueued on it too, so one synchronize covers the whole step
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
     lib = ctx.lib
     dp = gsmcal._lib.c_double_p

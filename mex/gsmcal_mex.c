@@ -1,0 +1,172 @@
+/* gsmcal_mex.c -- MEX gateway: lets gsm_sync_demod.m / multi_rtl_sdr_gsm_FCCH_scanner.m call the
+ * MI355X kernels through the reference's own function names, unchanged.
+ *
+ * NOT compiled in the build image (no MATLAB, no mex.h); it is the binding a maintainer of the
+ * reference would add.  Build one MEX file per function, named like the .m file it shadows, and put
+ * the output directory ahead of the reference on the MATLAB path:
+ *
+ *   for f in raw2iq chn_filter_8x_4x move_fft_snr_runtime_avg specific_fft_snr_fix_avg \
+ *            FCCH_coarse_position FCCH_fine_correction SCH_corr_rate_correction \
+ *            carrier_correct_post_SCH total_ppm_calculation; do
+ *     mex -R2018a -DGSMCAL_FN_$f -output $f mex/gsmcal_mex.c -Iinclude -Lmulti-rtl-sdr-calibration_amd/lib -lgsmcal
+ *   done
+ *
+ * -R2018a selects the interleaved-complex API, which matches the ABI's interleaved double[2].
+ * Argument lists, 1-based positions, row/column shapes and sentinels follow the .m files
+ * (cited per function); negative ABI status codes become mexErrMsgIdAndTxt errors, positive ones
+ * (reference sentinels) return normally with the sentinel outputs, as the .m files do.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "gsmcal.h"
+#include "mex.h"
+
+static gsmcal_ctx* g_ctx = NULL;
+
+static void at_exit(void) {
+    if (g_ctx) { gsmcal_ctx_destroy(g_ctx); g_ctx = NULL; }
+}
+
+static gsmcal_ctx* ctx(void) {   /* created lazily, like the `persistent coef` of chn_filter_8x_4x.m:6-11 */
+    if (!g_ctx) {
+        if (gsmcal_ctx_create(0, &g_ctx) != 0) mexErrMsgIdAndTxt("gsmcal:nodevice", "no usable MI355X (gfx950) device");
+        mexAtExit(at_exit);
+    }
+    return g_ctx;
+}
+
+static void chk(int rc, const char* what) {
+    if (rc < 0) mexErrMsgIdAndTxt("gsmcal:error", "%s failed (%d): %s", what, rc, gsmcal_last_error(g_ctx));
+}
+
+static const double* cplx_in(const mxArray* a, mwSize* n) {   /* complex (or real, widened) vector -> interleaved */
+    *n = mxGetNumberOfElements(a);
+    if (mxIsComplex(a)) return (const double*)mxGetComplexDoubles(a);
+    {
+        double* t = (double*)mxCalloc(2 * (*n), sizeof(double));
+        const double* r = mxGetDoubles(a);
+        mwSize i;
+        for (i = 0; i < *n; ++i) t[2 * i] = r[i];
+        return t;
+    }
+}
+
+static mxArray* scalar(double v) { return mxCreateDoubleScalar(v); }
+
+static mxArray* cplx_col(const double* data, mwSize n) {
+    mxArray* o = mxCreateDoubleMatrix(n, 1, mxCOMPLEX);
+    memcpy(mxGetComplexDoubles(o), data, 2 * n * sizeof(double));
+    return o;
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+#if defined(GSMCAL_FN_raw2iq)
+    /* b = raw2iq(a)                                   raw2iq.m:5 */
+    mwSize rows = mxGetM(prhs[0]), d = mxGetN(prhs[0]);
+    plhs[0] = mxCreateDoubleMatrix(rows / 2, d, mxCOMPLEX);
+    chk(gsmcal_raw2iq(ctx(), mxGetDoubles(prhs[0]), (long)rows, (int)d, (double*)mxGetComplexDoubles(plhs[0])), "raw2iq");
+
+#elif defined(GSMCAL_FN_chn_filter_8x_4x)
+    /* r = chn_filter_8x_4x(s)                         chn_filter_8x_4x.m:5 */
+    mwSize n = mxGetM(prhs[0]), d = mxGetN(prhs[0]), tot;
+    const double* s = cplx_in(prhs[0], &tot);
+    plhs[0] = mxCreateDoubleMatrix((n + 1) / 2, d, mxCOMPLEX);
+    chk(gsmcal_chn_filter_8x_4x(ctx(), s, (long)n, (int)d, NULL, 0, (double*)mxGetComplexDoubles(plhs[0])), "chn_filter_8x_4x");
+
+#elif defined(GSMCAL_FN_move_fft_snr_runtime_avg)
+    /* [hit_flag,hit_idx,hit_avg_snr,hit_snr] = move_fft_snr_runtime_avg(s,mv_len,fft_len,th) */
+    mwSize n;
+    const double* s = cplx_in(prhs[0], &n);
+    int hf; double hi, ha, hs;
+    chk(gsmcal_move_fft_snr_runtime_avg(ctx(), s, (long)n, (int)mxGetScalar(prhs[1]), (int)mxGetScalar(prhs[2]),
+                                        mxGetScalar(prhs[3]), &hf, &hi, &ha, &hs), "move_fft_snr_runtime_avg");
+    plhs[0] = mxCreateLogicalScalar(hf != 0);
+    if (nlhs > 1) plhs[1] = scalar(hi);
+    if (nlhs > 2) plhs[2] = scalar(ha);
+    if (nlhs > 3) plhs[3] = scalar(hs);
+
+#elif defined(GSMCAL_FN_specific_fft_snr_fix_avg)
+    /* [hit_flag,hit_idx,hit_snr] = specific_fft_snr_fix_avg(s,target_set,fft_len,th,avg_snr) */
+    mwSize n;
+    const double* s = cplx_in(prhs[0], &n);
+    int hf; double hi, hs;
+    chk(gsmcal_specific_fft_snr_fix_avg(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetScalar(prhs[2]),
+                                        mxGetScalar(prhs[3]), mxGetScalar(prhs[4]), &hf, &hi, &hs),
+        "specific_fft_snr_fix_avg");
+    plhs[0] = mxCreateLogicalScalar(hf != 0);
+    if (nlhs > 1) plhs[1] = scalar(hi);
+    if (nlhs > 2) plhs[2] = scalar(hs);
+
+#elif defined(GSMCAL_FN_FCCH_coarse_position)
+    /* [position,snr] = FCCH_coarse_position(s,decimation_ratio)     (row vectors; -1,-1 when none) */
+    mwSize n;
+    const double* s = cplx_in(prhs[0], &n);
+    double pos[GSMCAL_MAX_HITS], snr[GSMCAL_MAX_HITS];
+    int cnt = 0;
+    chk(gsmcal_FCCH_coarse_position(ctx(), s, (long)n, (int)mxGetScalar(prhs[1]), pos, snr, GSMCAL_MAX_HITS, &cnt),
+        "FCCH_coarse_position");
+    plhs[0] = mxCreateDoubleMatrix(1, cnt, mxREAL);
+    memcpy(mxGetDoubles(plhs[0]), pos, cnt * sizeof(double));
+    if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, cnt, mxREAL); memcpy(mxGetDoubles(plhs[1]), snr, cnt * sizeof(double)); }
+
+#elif defined(GSMCAL_FN_FCCH_fine_correction)
+    /* [FCCH_pos,r,sampling_ppm,carrier_ppm] = FCCH_fine_correction(s,base_position,ov,carrier_freq) */
+    mwSize n;
+    const double* s = cplx_in(prhs[0], &n);
+    double pos[GSMCAL_MAX_HITS], sp, cp;
+    int npos = 0; long lr = -1;
+    double* r = (double*)mxMalloc(2 * n * sizeof(double));
+    chk(gsmcal_FCCH_fine_correction(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
+                                    (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), pos, GSMCAL_MAX_HITS, &npos,
+                                    r, (long)n, &lr, &sp, &cp), "FCCH_fine_correction");
+    plhs[0] = mxCreateDoubleMatrix(1, npos, mxREAL);
+    memcpy(mxGetDoubles(plhs[0]), pos, npos * sizeof(double));
+    if (nlhs > 1) plhs[1] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
+    if (nlhs > 2) plhs[2] = scalar(sp);
+    if (nlhs > 3) plhs[3] = scalar(cp);
+    mxFree(r);
+
+#elif defined(GSMCAL_FN_SCH_corr_rate_correction)
+    /* [pos_info,r,sampling_ppm] = SCH_corr_rate_correction(s,FCCH_pos,sch_training_sequence,ov) */
+    mwSize n = 0, nts;
+    const double* s = mxGetNumberOfElements(prhs[0]) > 1 ? cplx_in(prhs[0], &n) : NULL;   /* r = -1 upstream */
+    const double* ts = cplx_in(prhs[2], &nts);
+    double pi[2 * GSMCAL_MAX_POS_ROWS], sp;
+    int rows = 0, i; long lr = -1;
+    double* r = n ? (double*)mxMalloc(2 * n * sizeof(double)) : NULL;
+    chk(gsmcal_SCH_corr_rate_correction(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
+                                        ts, (int)nts, (int)mxGetScalar(prhs[3]), pi, GSMCAL_MAX_POS_ROWS, &rows,
+                                        r, (long)n, &lr, &sp), "SCH_corr_rate_correction");
+    plhs[0] = mxCreateDoubleMatrix(rows, 2, mxREAL);
+    for (i = 0; i < rows; ++i) {
+        mxGetDoubles(plhs[0])[i] = pi[i];
+        mxGetDoubles(plhs[0])[rows + i] = pi[GSMCAL_MAX_POS_ROWS + i];
+    }
+    if (nlhs > 1) plhs[1] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
+    if (nlhs > 2) plhs[2] = scalar(sp);
+    if (r) mxFree(r);
+
+#elif defined(GSMCAL_FN_carrier_correct_post_SCH)
+    /* [r,carrier_ppm] = carrier_correct_post_SCH(s,pos_info,ov,carrier_freq) */
+    mwSize n = 0;
+    const double* s = mxGetNumberOfElements(prhs[0]) > 1 ? cplx_in(prhs[0], &n) : NULL;
+    int rows = (int)mxGetM(prhs[1]);
+    double cp; long lr = -1;
+    double* r = n ? (double*)mxMalloc(2 * n * sizeof(double)) : NULL;
+    chk(gsmcal_carrier_correct_post_SCH(ctx(), s, (long)n, mxGetDoubles(prhs[1]), rows, rows, (int)mxGetScalar(prhs[2]),
+                                        mxGetScalar(prhs[3]), r, (long)n, &lr, &cp), "carrier_correct_post_SCH");
+    plhs[0] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
+    if (nlhs > 1) plhs[1] = scalar(cp);
+    if (r) mxFree(r);
+
+#elif defined(GSMCAL_FN_total_ppm_calculation)
+    /* ppm_out = total_ppm_calculation(ppm_in) */
+    double out;
+    gsmcal_total_ppm_calculation(mxGetDoubles(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out);
+    plhs[0] = scalar(out);
+#else
+#error "define one GSMCAL_FN_<function> (see the header comment)"
+#endif
+    (void)nrhs;
+}

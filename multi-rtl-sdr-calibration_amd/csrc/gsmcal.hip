@@ -36,13 +36,41 @@ struct ProfRec {
 
 }  // namespace
 
+// A lane = one HIP stream + the per-stream-group scratch of the chain.  A batch is split over several
+// lanes so that one group's latency-bound stages (coarse scan, decisions, small FFTs) run underneath
+// another group's compute-bound fine search.  Lane 0 runs on the context's own stream.
+#define MAX_LANES 8
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf state, dec, win, peaks, snrbuf, x0;
+    hipEvent_t done = nullptr;
+    int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
+};
+
 struct gsmcal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    // workspace
-    DevBuf state, coef, ts, cf, dec, win, peaks, snrbuf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, x0;
+    Lane lanes[MAX_LANES];
+    Lane* cur = nullptr;        // lane the helpers below enqueue on
+    int n_lanes_cfg = 1;        // GSMCAL_LANES (multi-lane dispatch is kept for experiments)
+    int n_lanes_used = 1;
+    const double* cf_lane = nullptr;   // carrier_freq of the current lane's first stream (batch path)
+    hipEvent_t fork = nullptr;
+    // hipGraph replay of a repeated batch call (same pointers, sizes and parameters as the previous call)
+    struct GraphSlot {
+        std::vector<uintptr_t> key;
+        unsigned long epoch = 0;
+        int seen = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    } g_calib, g_scan;
+    unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
+    bool use_graph = true;          // GSMCAL_GRAPH=0 disables
+    bool capturing = false;
+    // shared workspace
+    DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;
     int tw_n = 0;                            // length the twiddle table was built for
     std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
     int last_S = 0;
@@ -76,7 +104,7 @@ namespace {
 int ensure(gsmcal_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
     if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -84,6 +112,7 @@ int ensure(gsmcal_ctx* c, DevBuf& b, size_t bytes) {
     size_t want = bytes + bytes / 8 + 256;
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
+    ++c->ws_epoch;
     return 0;
 }
 
@@ -109,7 +138,8 @@ hipEvent_t get_event(gsmcal_ctx* c) {
 
 int prof_flush(gsmcal_ctx* c) {
     if (c->prof_pending.empty()) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < MAX_LANES; ++i)
+        if (c->lanes[i].stream || i == 0) HIPCHK(c, hipStreamSynchronize(c->lanes[i].stream));
     for (auto& r : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -133,12 +163,12 @@ struct ProfScope {
             r.name_id = prof_id(c, name);
             r.e0 = get_event(c);
             r.e1 = get_event(c);
-            (void)hipEventRecord(r.e0, c->stream);
+            (void)hipEventRecord(r.e0, c->cur->stream);
         }
     }
     ~ProfScope() {
         if (on) {
-            (void)hipEventRecord(r.e1, c->stream);
+            (void)hipEventRecord(r.e1, c->cur->stream);
             c->prof_pending.push_back(r);
             if (c->prof_pending.size() > 60000) (void)prof_flush(c);
         }
@@ -148,7 +178,7 @@ struct ProfScope {
 #define LAUNCH(c, kern, grid, block, shmem, ...)                                  \
     do {                                                                          \
         ProfScope ps__(c, #kern);                                                 \
-        hipLaunchKernelGGL(kern, grid, block, shmem, (c)->stream, __VA_ARGS__);   \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (c)->cur->stream, __VA_ARGS__);   \
     } while (0)
 
 #define CHECK_LAUNCH(c) HIPCHK(c, hipGetLastError())
@@ -157,6 +187,7 @@ int upload_cached(gsmcal_ctx* c, DevBuf& b, std::vector<double>& host, const dou
     if (host.size() == n && b.p && memcmp(host.data(), src, n * sizeof(double)) == 0) return 0;
     RET_IF(ensure(c, b, n * sizeof(double)));
     host.assign(src, src + n);
+    ++c->ws_epoch;
     HIPCHK(c, hipMemcpyAsync(b.p, host.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
@@ -196,7 +227,7 @@ int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, b
     a.raw = src.raw; a.raw_stride = src.raw_stride; a.arr = src.arr; a.arr_stride = src.arr_stride;
     a.coef = src.coef; a.dst = dst; a.dst_stream_stride = dst_stream_stride; a.dst_win_stride = dst_win_stride;
     const size_t lds = gather_lds(len, level, src.kind, src.ntaps);
-    LAUNCH(c, k_gather, dim3(nwin_grid, S), dim3(256), lds, (const StreamState*)c->state.p, a);
+    LAUNCH(c, k_gather, dim3(nwin_grid, S), dim3(256), lds, (const StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -207,6 +238,7 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
     LAUNCH(c, k_make_twiddles, dim3((nfft + 255) / 256), dim3(256), 0, (cplx*)c->tw.p, nfft);
     CHECK_LAUNCH(c);
     c->tw_n = nfft;
+    ++c->ws_epoch;
     return 0;
 }
 
@@ -218,8 +250,8 @@ StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
     StepArgs a;
     memset(&a, 0, sizeof(a));
     a.ov = g.ov; a.H = H; a.NB = g.NB; a.len_ts = len_ts;
-    a.peaks = (const PeakOut*)c->peaks.p;
-    a.carrier_freq = (const double*)c->cf.p;
+    a.peaks = (const PeakOut*)c->cur->peaks.p;
+    a.carrier_freq = c->cf_lane ? c->cf_lane : (const double*)c->cf.p;
     return a;
 }
 
@@ -228,21 +260,21 @@ StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
 // next_sch_lvl >= 0: also run SCH_corr_rate_correction's window setup in the last decision launch.
 int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, bool setup_done,
              int next_sch_lvl, int len_ts) {
-    StreamState* st = (StreamState*)c->state.p;
+    StreamState* st = (StreamState*)c->cur->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
-    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
-    RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
-    RET_IF(ensure(c, c->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
+    RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
+    RET_IF(ensure(c, c->cur->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    RET_IF(ensure(c, c->cur->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
     RET_IF(ensure_twiddles(c, g.nfft));
-    cplx* win = (cplx*)c->win.p;
-    PeakOut* peaks = (PeakOut*)c->peaks.p;
+    cplx* win = (cplx*)c->cur->win.p;
+    PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
-           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->x0.p, H);
-    LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1) * sizeof(cplx),
-           (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->x0.p,
+           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H);
+    LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
+           (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
            peaks, H, g.NB);
     LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1
@@ -263,11 +295,11 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
 // ---- SCH_corr_rate_correction body (input at level lvl; creates level lvl+1) ----
 int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, int len_ts, bool setup_done,
             int next_post_lvl) {
-    StreamState* st = (StreamState*)c->state.p;
+    StreamState* st = (StreamState*)c->cur->state.p;
     const int wl = g.sch_nshift - 1 + len_ts;
     const long wstride = g.fine_wlen > wl ? g.fine_wlen : wl, sstride = (long)H * wstride;
-    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
-    cplx* win = (cplx*)c->win.p;
+    RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
+    cplx* win = (cplx*)c->cur->win.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     RET_IF(launch_gather(c, S, src, lvl, wl, false, H, win, sstride, wstride));
@@ -286,13 +318,13 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
 // table != nullptr: also write the calibration table row (gsm_sync_demod.m:123-124) in the last launch.
 int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, bool setup_done, double* table,
              double* pos_info_out, long* r_len_out) {
-    StreamState* st = (StreamState*)c->state.p;
+    StreamState* st = (StreamState*)c->cur->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
-    RET_IF(ensure(c, c->win, (size_t)S * sstride * sizeof(cplx)));
-    RET_IF(ensure(c, c->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
+    RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
+    RET_IF(ensure(c, c->cur->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
     RET_IF(ensure_twiddles(c, g.nfft));
-    cplx* win = (cplx*)c->win.p;
-    PeakOut* peaks = (PeakOut*)c->peaks.p;
+    cplx* win = (cplx*)c->cur->win.p;
+    PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
     StepArgs sa = step_args(c, g, H, 0);
     sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
@@ -312,8 +344,8 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
 
 int init_states(gsmcal_ctx* c, int S, long n0) {
     (void)n0;   // written with the other defaults by k_finish_mean
-    RET_IF(ensure(c, c->state, (size_t)S * sizeof(StreamState)));
-    HIPCHK(c, hipMemsetAsync(c->state.p, 0, (size_t)S * sizeof(StreamState), c->stream));
+    RET_IF(ensure(c, c->cur->state, (size_t)S * sizeof(StreamState)));
+    HIPCHK(c, hipMemsetAsync(c->cur->state.p, 0, (size_t)S * sizeof(StreamState), c->cur->stream));
     c->last_S = S;
     return 0;
 }
@@ -324,8 +356,8 @@ int dc_means(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n) {
     int cap = 4096 / (S > 0 ? S : 1);
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
-    LAUNCH(c, k_dc_sum, dim3(blocks, S), dim3(256), 0, d_raw, 2 * n, (StreamState*)c->state.p);
-    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->state.p, S, n);
+    LAUNCH(c, k_dc_sum, dim3(blocks, S), dim3(256), 0, d_raw, 2 * n, (StreamState*)c->cur->state.p);
+    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->cur->state.p, S, n);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -337,7 +369,7 @@ int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const doub
     const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
     if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_fir_decim_raw, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
-           (const StreamState*)c->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
+           (const StreamState*)c->cur->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -363,24 +395,24 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     const long nwin = n_first - (fft_len - 1);
     const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
-    RET_IF(ensure(c, c->snrbuf, (size_t)S * nwin * sizeof(double)));
-    a.snr_g = (double*)c->snrbuf.p; a.snr_stride = nwin;
+    RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
+    a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
     LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
-    LAUNCH(c, k_coarse_scan, dim3(S), dim3(256), lds, (StreamState*)c->state.p, a);
+    LAUNCH(c, k_coarse_scan, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     return 0;
 }
 
 int fetch_states(gsmcal_ctx* c, int S, std::vector<StreamState>& out) {
     out.resize(S);
-    HIPCHK(c, hipMemcpyAsync(out.data(), c->state.p, (size_t)S * sizeof(StreamState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->cur->state.p, (size_t)S * sizeof(StreamState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int push_states(gsmcal_ctx* c, const std::vector<StreamState>& in) {
-    RET_IF(ensure(c, c->state, in.size() * sizeof(StreamState)));
-    HIPCHK(c, hipMemcpyAsync(c->state.p, in.data(), in.size() * sizeof(StreamState), hipMemcpyHostToDevice, c->stream));
+    RET_IF(ensure(c, c->cur->state, in.size() * sizeof(StreamState)));
+    HIPCHK(c, hipMemcpyAsync(c->cur->state.p, in.data(), in.size() * sizeof(StreamState), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -407,6 +439,91 @@ int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
     RET_IF(ensure(c, c->arr_in, n_cplx * sizeof(cplx)));
     HIPCHK(c, hipMemcpyAsync(c->arr_in.p, s, n_cplx * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     return 0;
+}
+
+// Split d units over the lanes: returns the number of lanes used and fills lo/n per lane.
+int plan_lanes(gsmcal_ctx* c, int d) {
+    int nl = c->n_lanes_cfg;
+    if (nl > d / 8) nl = d / 8;          // keep at least 8 streams per lane
+    if (nl < 1) nl = 1;
+    for (int i = 0; i < nl; ++i) {
+        c->lanes[i].lo = (int)(((long)i * d) / nl);
+        c->lanes[i].n = (int)(((long)(i + 1) * d) / nl) - c->lanes[i].lo;
+    }
+    for (int i = nl; i < MAX_LANES; ++i) c->lanes[i].n = 0;
+    c->n_lanes_used = nl;
+    return nl;
+}
+
+int fork_lanes(gsmcal_ctx* c, int nl) {
+    if (nl <= 1) return 0;
+    if (!c->fork) HIPCHK(c, hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->fork, c->stream));
+    for (int i = 1; i < nl; ++i) {
+        Lane& L = c->lanes[i];
+        if (!L.stream) HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if (!L.done) HIPCHK(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        HIPCHK(c, hipStreamWaitEvent(L.stream, c->fork, 0));
+    }
+    return 0;
+}
+
+int join_lanes(gsmcal_ctx* c, int nl) {
+    for (int i = 1; i < nl; ++i) {
+        HIPCHK(c, hipEventRecord(c->lanes[i].done, c->lanes[i].stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->lanes[i].done, 0));
+    }
+    c->cur = &c->lanes[0];
+    return 0;
+}
+
+// Run `enqueue` (which only enqueues work on the context's streams) eagerly, or -- from the third
+// identical call on -- as a captured hipGraph replayed with one hipGraphLaunch.  The first two calls
+// run eagerly so that every workspace buffer, lane stream and event exists before capture starts.
+template <class F>
+int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vector<uintptr_t>& key, F enqueue) {
+    const bool same = c->use_graph && !c->prof && slot.key == key && slot.epoch == c->ws_epoch;
+    if (same && slot.exec) {
+        HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
+        return 0;
+    }
+    if (!same) {
+        if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+        if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
+        slot.seen = 0;
+    }
+    if (same && slot.seen >= 1) {
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        c->capturing = true;
+        const int rc = enqueue();
+        c->capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc < 0 || e != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            c->use_graph = false;                       // fall back to eager launches for good
+            if (rc < 0) return rc;
+            return enqueue();
+        }
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(g);
+            c->use_graph = false;
+            return enqueue();
+        }
+        slot.graph = g;
+        slot.exec = ex;
+        HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
+        return 0;
+    }
+    const int rc = enqueue();
+    if (rc < 0) return rc;
+    // the call may have allocated / uploaded: remember the state AFTER it
+    slot.key = key;
+    slot.epoch = c->ws_epoch;
+    slot.seen = same ? slot.seen + 1 : 1;
+    if (!same) slot.seen = 1;
+    return rc;
 }
 
 int positive_status(const StreamState& st, int stage) {
@@ -441,6 +558,12 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     c->device = device_id;
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    c->lanes[0].stream = c->stream;
+    c->cur = &c->lanes[0];
+    const char* e = getenv("GSMCAL_LANES");
+    if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
+    const char* ge = getenv("GSMCAL_GRAPH");
+    if (ge && atoi(ge) == 0) c->use_graph = false;
     *out = c;
     return 0;
 }
@@ -455,6 +578,7 @@ int gsmcal_ctx_create(int device_id, gsmcal_ctx** out) {
         return GSMCAL_E_HIP;
     }
     c->own_stream = true;
+    c->lanes[0].stream = c->stream;
     return 0;
 }
 
@@ -462,10 +586,24 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->state, &c->coef, &c->ts, &c->cf, &c->dec, &c->win, &c->peaks, &c->snrbuf, &c->table,
-                      &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen, &c->misc, &c->tw, &c->x0};
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = {&c->coef, &c->ts, &c->cf, &c->table, &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen,
+                      &c->misc, &c->tw};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < MAX_LANES; ++i) {
+        Lane& L = c->lanes[i];
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0};
+        for (DevBuf* b : lb)
+            if (b->p) (void)hipFree(b->p);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (auto* g : {&c->g_calib, &c->g_scan}) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+    }
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -548,7 +686,7 @@ int gsmcal_raw2iq_u8(gsmcal_ctx* c, const uint8_t* a, long rows_2n, int d, doubl
     int blocks = (int)((n + 256 * 4 - 1) / (256 * 4));
     if (blocks > 2048) blocks = 2048;
     LAUNCH(c, k_raw2iq, dim3(blocks, d), dim3(256), 0, (const uint8_t*)c->misc.p, rows_2n,
-           (const StreamState*)c->state.p, (cplx*)c->arr_out.p, n);
+           (const StreamState*)c->cur->state.p, (cplx*)c->arr_out.p, n);
     CHECK_LAUNCH(c);
     HIPCHK(c, hipMemcpyAsync(b, c->arr_out.p, (size_t)n * d * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -599,7 +737,7 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
     std::vector<StreamState> v(1);
     host_init_state(v[0], len);
     RET_IF(push_states(c, v));
-    c->last_S = 1;
+    c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     a.s = (const cplx*)c->arr_in.p; a.s_stride = len; a.len = len;
     int fft_len = a.fft_len;
     long n_first = len;
@@ -612,11 +750,11 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
     const size_t lds = coarse_scan_lds(n_first > 0 ? n_first : 0, a.mode == 0 ? 10 * fft_len : a.mv_len);
     if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
     if (a.mode != 2 && nwin >= 1 && n_first <= len) {
-        RET_IF(ensure(c, c->snrbuf, (size_t)nwin * sizeof(double)));
-        a.snr_g = (double*)c->snrbuf.p; a.snr_stride = nwin;
+        RET_IF(ensure(c, c->cur->snrbuf, (size_t)nwin * sizeof(double)));
+        a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
         LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
     }
-    LAUNCH(c, k_coarse_scan, dim3(1), dim3(256), lds, (StreamState*)c->state.p, a);
+    LAUNCH(c, k_coarse_scan, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     RET_IF(fetch_states(c, 1, v));
     *out = v[0];
@@ -691,7 +829,7 @@ int gsmcal_FCCH_fine_correction(gsmcal_ctx* c, const double* s, long len, const 
     v[0].n_coarse = num_base;
     for (int i = 0; i < num_base; ++i) v[0].coarse_pos[i] = base_position[i];
     RET_IF(push_states(c, v));
-    c->last_S = 1;
+    c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_base > 0 ? num_base : 1;
     RET_IF(run_fine(c, 1, src, 0, g, H, false, -1, 0));
@@ -742,7 +880,7 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
     for (int i = 0; i < num_fcch; ++i) v[0].fcch_pos[i] = fcch_pos[i];
     if (!have_s && !(sentinel_in || num_fcch < 5)) return GSMCAL_E_ARG;
     RET_IF(push_states(c, v));
-    c->last_S = 1;
+    c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_fcch > 0 ? num_fcch : 1;
     RET_IF(run_sch(c, 1, src, 0, g, H, len_ts, false, -1));
@@ -801,7 +939,7 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, co
     }
     if (nfcch > MAXH) return GSMCAL_E_CAPACITY;
     RET_IF(push_states(c, v));
-    c->last_S = 1;
+    c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     RET_IF(run_post(c, 1, src, 0, g, nfcch > 0 ? nfcch : 1, false, nullptr, nullptr, nullptr));
     RET_IF(fetch_states(c, 1, v));
@@ -834,6 +972,8 @@ int gsmcal_frontend_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n
                               int decim, double* d_out) {
     if (!c || !d_raw || !coef || !d_out || d < 1 || n < 1 || ntaps < 1 || decim < 1) return GSMCAL_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    c->cur = &c->lanes[0];
+    c->lanes[0].lo = 0; c->lanes[0].n = d; c->n_lanes_used = 1;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(init_states(c, d, n));
     RET_IF(dc_means(c, d_raw, d, n));
@@ -862,17 +1002,40 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // ..FCCH_scanner.m:43-45
     const long nd = (n + decim - 1) / decim;
     if (hits_capacity(nd, dec_ratio) > MAXH) return GSMCAL_E_CAPACITY;
+    c->cur = &c->lanes[0];
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
-    RET_IF(ensure(c, c->dec, (size_t)d * nd * sizeof(cplx)));
-    RET_IF(init_states(c, d, n));
-    RET_IF(dc_means(c, d_raw, d, n));
-    RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));
-    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio, 0));
-    StepArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.snr_numhit = d_snr_numhit; sa.positions = d_positions; sa.pos_snr = d_pos_snr; sa.counts = d_counts;
-    LAUNCH(c, k_step<STEP_SCAN_ACCEPT>, dim3(d), dim3(64), 0, (StreamState*)c->state.p, sa, 0, 0);
-    CHECK_LAUNCH(c);
+    const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
+                                        (uintptr_t)d_snr_numhit, (uintptr_t)d_positions, (uintptr_t)d_pos_snr,
+                                        (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg};
+    auto enqueue = [&]() -> int {
+    const int nl = plan_lanes(c, d);
+    RET_IF(fork_lanes(c, nl));
+    for (int i = 0; i < nl; ++i) {
+        Lane& L = c->lanes[i];
+        c->cur = &L;
+        const int lo = L.lo, S = L.n;
+        const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
+        RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
+        RET_IF(init_states(c, S, n));
+        RET_IF(dc_means(c, raw_i, S, n));
+        RET_IF(fir_decim_raw(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0));
+        StepArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
+        sa.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
+        sa.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
+        sa.counts = d_counts ? d_counts + lo : nullptr;
+        LAUNCH(c, k_step<STEP_SCAN_ACCEPT>, dim3(S), dim3(64), 0, (StreamState*)L.state.p, sa, 0, 0);
+        CHECK_LAUNCH(c);
+    }
+    RET_IF(join_lanes(c, nl));
+    return 0;
+    };
+    RET_IF(run_maybe_graph(c, c->g_scan, key, enqueue));
+    plan_lanes(c, d);
+    c->cur = &c->lanes[0];
+    c->last_S = d;
     return 0;
 }
 
@@ -909,22 +1072,50 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     const long nd = (n + decim - 1) / decim;
     int H = hits_capacity(nd, dec_ratio) + 1;
     if (H > MAXH) return GSMCAL_E_CAPACITY;
+    c->cur = &c->lanes[0];
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
     RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));
-    RET_IF(ensure(c, c->dec, (size_t)d * nd * sizeof(cplx)));
-    RET_IF(init_states(c, d, n));
-    RET_IF(dc_means(c, d_raw, d, n));                                                  // raw2iq.m:8
-    RET_IF(fir_decim_raw(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)c->dec.p, nd));  // :107,110,117
-    RET_IF(coarse(c, d, (const cplx*)c->dec.p, nd, nd, dec_ratio, ov));                // :117 (+ fine window setup)
-    Source src{SRC_RAW, d_raw, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
-    RET_IF(run_fine(c, d, src, 0, g, H, true, 2, len_ts));                             // :118 (+ SCH window setup)
-    RET_IF(run_sch(c, d, src, 2, g, H, len_ts, true, 3));                              // :119 (+ post-SCH window setup)
-    RET_IF(run_post(c, d, src, 3, g, H, true, d_table, d_pos_info, d_r_len));          // :120, :123-124
-    if (d_r_correct) {
-        const int tiles = (int)((n + TILE - 1) / TILE);
-        RET_IF(launch_gather(c, d, src, 4, TILE, true, tiles, (cplx*)d_r_correct, n, 0));
+    RET_IF(ensure_twiddles(c, g.nfft));
+    // independent streams: split over lanes (HIP streams) so latency-bound stages of one group overlap the
+    // compute-bound fine search of another; a repeated call is replayed as one hipGraph
+    const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps, (uintptr_t)len_ts,
+                                        (uintptr_t)d_table, (uintptr_t)d_pos_info, (uintptr_t)d_r_correct,
+                                        (uintptr_t)d_r_len, (uintptr_t)c->n_lanes_cfg};
+    auto enqueue = [&]() -> int {
+    const int nl = plan_lanes(c, d);
+    RET_IF(fork_lanes(c, nl));
+    const double* cf_all = (const double*)c->cf.p;
+    for (int i = 0; i < nl; ++i) {
+        Lane& L = c->lanes[i];
+        c->cur = &L;
+        const int lo = L.lo, S = L.n;
+        const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
+        RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
+        RET_IF(init_states(c, S, n));
+        RET_IF(dc_means(c, raw_i, S, n));                                                   // raw2iq.m:8
+        RET_IF(fir_decim_raw(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov));                  // :117 (+ fine window setup)
+        Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
+        c->cf_lane = cf_all + lo;
+        RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts));                              // :118 (+ SCH window setup)
+        RET_IF(run_sch(c, S, src, 2, g, H, len_ts, true, 3));                               // :119 (+ post-SCH window setup)
+        RET_IF(run_post(c, S, src, 3, g, H, true, d_table + (size_t)lo * GSMCAL_TABLE_COLS,
+                        d_pos_info ? d_pos_info + (size_t)lo * 2 * MAXROWS : nullptr,
+                        d_r_len ? d_r_len + lo : nullptr));                                 // :120, :123-124
+        if (d_r_correct) {
+            const int tiles = (int)((n + TILE - 1) / TILE);
+            RET_IF(launch_gather(c, S, src, 4, TILE, true, tiles, (cplx*)d_r_correct + (size_t)lo * n, n, 0));
+        }
     }
+    c->cf_lane = nullptr;
+    RET_IF(join_lanes(c, nl));
+    return 0;
+    };
+    RET_IF(run_maybe_graph(c, c->g_calib, key, enqueue));
+    plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
+    c->cur = &c->lanes[0];
+    c->last_S = d;
     return 0;
 }
 
@@ -955,8 +1146,15 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
 int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* coarse_snr, double* fine_first,
                               double* fcch_pos, double* sch_first, int* counts) {
     if (!c || d < 1 || d > c->last_S) return GSMCAL_E_ARG;
-    std::vector<StreamState> v;
-    RET_IF(fetch_states(c, d, v));
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<StreamState> v((size_t)c->last_S);
+    if (c->n_lanes_used <= 1 && c->lanes[0].n == 0) { c->lanes[0].lo = 0; c->lanes[0].n = c->last_S; }
+    for (int i = 0; i < c->n_lanes_used; ++i) {
+        const Lane& L = c->lanes[i];
+        if (L.n <= 0 || L.lo + L.n > c->last_S) continue;
+        HIPCHK(c, hipMemcpy(v.data() + L.lo, L.state.p, (size_t)L.n * sizeof(StreamState), hipMemcpyDeviceToHost));
+    }
     for (int s = 0; s < d; ++s) {
         const StreamState& st = v[s];
         for (int i = 0; i < MAXH; ++i) {

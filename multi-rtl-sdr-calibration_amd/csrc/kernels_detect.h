@@ -483,17 +483,23 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 // Fine search, FCCH_fine_correction.m:48-52: argmax over the nshift = 128*ov+1 window starts of
 // max_k |FFT_nfft(window)|^2, as an exact sliding DFT in fp64: one bin per lane,
 //   X_k(m+1) = (X_k(m) + x[m+nfft] - x[m]) * exp(+2*pi*i*k/nfft),   X_k(0) from k_fft_burst<1>.
-// Each lane keeps its best (power, first m); the block reduces with "larger power, then smaller m",
-// which is MATLAB's first-max rule for max(max(|fft|^2,[],1)).
+// The hot loop is VALU-issue bound (every instruction costs ~4 cycles per wave), so it carries
+// only the recurrence (6 fp64 ops), |X|^2 (2) and ONE v_max_f64: steps are processed in chunks of
+// FS_CHUNK; per chunk the lane keeps the chunk maximum, and only when a chunk beats the running best
+// (strictly) does it remember the chunk index and the state the chunk started from.  After the loop
+// the block reduces to its winning lane ("larger power, then smaller start" = MATLAB's first-max rule
+// for max(max(|fft|^2,[],1))), and that lane alone replays its winning chunk -- the same operations
+// on the same operands, hence bit-identical powers -- to find the first step that attains the maximum.
 // grid (NB, H, S), block 256; bin k = blockIdx.x*256 + tid.  LDS: nshift-1 differences.
 // ------------------------------------------------------------------------------------------------
+#define FS_CHUNK 64
 __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restrict__ sts,
                                                      const cplx* __restrict__ win, long win_stream_stride,
                                                      long win_stride, int nshift, int nfft,
                                                      const cplx* __restrict__ x0, PeakOut* __restrict__ out,
                                                      int H, int NB) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* d = (cplx*)smem;                      // nshift-1 differences x[t+nfft]-x[t]
+    cplx* d = (cplx*)smem;                      // nshift-1 differences x[t+nfft]-x[t] (+ FS_CHUNK zero pad)
     __shared__ double red_p[4];
     __shared__ int red_t[4], red_k[4];
     const int s = blockIdx.z, w = blockIdx.y;
@@ -501,44 +507,86 @@ __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restri
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     const int tid = threadIdx.x;
     const int nstep = nshift - 1;
-    for (int t = tid; t < nstep; t += 256) {
-        const cplx a = x[t + nfft], b = x[t];
-        d[t] = make_double2(a.x - b.x, a.y - b.y);
+    const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
+    for (int t = tid; t < nstep_pad; t += 256) {
+        cplx v = make_double2(0.0, 0.0);
+        if (t < nstep) {
+            const cplx a = x[t + nfft], b = x[t];
+            v = make_double2(a.x - b.x, a.y - b.y);
+        }
+        d[t] = v;
     }
     __syncthreads();
     const int k = blockIdx.x * 256 + tid;
-    double best = -1.0;
-    int best_m = 0;
+    double best = -1.0;          // running best power of this bin
+    int best_c = -1;             // chunk that attained it (-1: the start window m = 0)
+    double sxr = 0.0, sxi = 0.0; // state at the start of that chunk
+    double wr = 1.0, wi = 0.0;
     if (k < nfft) {
-        double wi, wr;
         sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
         const cplx xi0 = x0[((size_t)s * H + w) * nfft + k];
         double xr = xi0.x, xi = xi0.y;
         best = xr * xr + xi * xi;               // window start m = 0
-#pragma unroll 4
-        for (int t = 0; t < nstep; ++t) {
-            const cplx dv = d[t];
-            const double ar = xr + dv.x, ai = xi + dv.y;
-            xr = ar * wr - ai * wi;
-            xi = ar * wi + ai * wr;
-            const double p = xr * xr + xi * xi;
-            if (p > best) { best = p; best_m = t + 1; }
+        const int nchunk = nstep_pad / FS_CHUNK;
+        for (int c = 0; c < nchunk; ++c) {
+            const double cxr = xr, cxi = xi;
+            double cmax = -1.0;
+            const cplx* dc = d + c * FS_CHUNK;
+            const int lim = nstep - c * FS_CHUNK;   // real steps in this chunk (< FS_CHUNK only in a ragged last chunk)
+            if (lim >= FS_CHUNK) {
+#pragma unroll 8
+                for (int j = 0; j < FS_CHUNK; ++j) {
+                    const cplx dv = dc[j];
+                    const double ar = xr + dv.x, ai = xi + dv.y;
+                    xr = ar * wr - ai * wi;
+                    xi = ar * wi + ai * wr;
+                    cmax = fmax(cmax, xr * xr + xi * xi);
+                }
+            } else {
+                for (int j = 0; j < lim; ++j) {
+                    const cplx dv = dc[j];
+                    const double ar = xr + dv.x, ai = xi + dv.y;
+                    xr = ar * wr - ai * wi;
+                    xi = ar * wi + ai * wr;
+                    cmax = fmax(cmax, xr * xr + xi * xi);
+                }
+            }
+            if (cmax > best) { best = cmax; best_c = c; sxr = cxr; sxi = cxi; }
         }
     }
-    int key = best_m, kk = k;
+    // block winner: larger power, then earlier chunk, then smaller bin
+    double rb = best;
+    int rc = k < nfft ? best_c : 0x7ffffff0, rk = k;
     for (int off = 32; off > 0; off >>= 1) {
-        const double op = __shfl_down(best, off, 64);
-        const int ok = __shfl_down(key, off, 64);
-        const int okk = __shfl_down(kk, off, 64);
-        if (op > best || (op == best && ok < key)) { best = op; key = ok; kk = okk; }
+        const double op = __shfl_down(rb, off, 64);
+        const int oc = __shfl_down(rc, off, 64);
+        const int ok = __shfl_down(rk, off, 64);
+        if (op > rb || (op == rb && (oc < rc || (oc == rc && ok < rk)))) { rb = op; rc = oc; rk = ok; }
     }
     const int wv = tid >> 6;
-    if ((tid & 63) == 0) { red_p[wv] = best; red_t[wv] = key; red_k[wv] = kk; }
+    if ((tid & 63) == 0) { red_p[wv] = rb; red_t[wv] = rc; red_k[wv] = rk; }
     __syncthreads();
-    if (tid == 0) {
-        for (int i = 1; i < 4; ++i)
-            if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; kk = red_k[i]; }
-        PeakOut o; o.p = best; o.tie = key; o.k = kk;
+    rb = red_p[0]; rc = red_t[0]; rk = red_k[0];
+    for (int i = 1; i < 4; ++i)
+        if (red_p[i] > rb || (red_p[i] == rb && (red_t[i] < rc || (red_t[i] == rc && red_k[i] < rk)))) {
+            rb = red_p[i]; rc = red_t[i]; rk = red_k[i];
+        }
+    if (k == rk) {                              // the winning lane locates the first step inside its chunk
+        int m = 0;
+        if (best_c >= 0) {
+            double xr = sxr, xi = sxi;
+            const cplx* dc = d + best_c * FS_CHUNK;
+            const int lim = nstep - best_c * FS_CHUNK < FS_CHUNK ? nstep - best_c * FS_CHUNK : FS_CHUNK;
+            for (int j = 0; j < lim; ++j) {
+                const cplx dv = dc[j];
+                const double ar = xr + dv.x, ai = xi + dv.y;
+                xr = ar * wr - ai * wi;
+                xi = ar * wi + ai * wr;
+                const double p = xr * xr + xi * xi;
+                if (p == best) { m = best_c * FS_CHUNK + j + 1; break; }
+            }
+        }
+        PeakOut o; o.p = best; o.tie = m; o.k = k;
         out[((size_t)s * H + w) * NB + blockIdx.x] = o;
     }
 }
