@@ -210,14 +210,30 @@ struct Source {
     const double* coef; int ntaps;
 };
 
-size_t gather_lds(int len, int level, int kind, int ntaps) {
-    // must mirror the carve at the top of k_gather
-    const size_t bufn = level >= 1 ? (size_t)len + 8 : 0;
-    size_t b = bufn * sizeof(cplx) * (level >= 2 ? 2 : 1) + (size_t)((ntaps + 1) & ~1) * 8;
+size_t gather_lds(int len, int level, int kind, int ntaps, bool to_lds = false) {
+    // must mirror the carve at the top of gather_core
+    const size_t bufn = (level >= 1 || to_lds) ? (size_t)len + 8 : 0;
+    size_t b = bufn * sizeof(cplx) * ((level >= 2 || to_lds) ? 2 : 1) + (size_t)((ntaps + 1) & ~1) * 8;
     const size_t span_max = (size_t)len + 8 + ntaps + 24;
     b += ((span_max + 7) & ~(size_t)7) * 2;
     if (kind == SRC_RAW) b += (span_max + span_max / 4 + 16) * sizeof(cplx);
     return (b + 15) & ~(size_t)15;
+}
+
+GatherArgs gather_args(const Source& src, int level, int len) {
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src_kind = src.kind; a.level = level; a.len = len; a.tiles = 0; a.ntaps = src.ntaps;
+    a.raw = src.raw; a.raw_stride = src.raw_stride; a.arr = src.arr; a.arr_stride = src.arr_stride;
+    a.coef = src.coef;
+    return a;
+}
+
+// LDS of a fused gather + estimator kernel: the gather carve, or the two window buffers plus `scratch`
+size_t fused_lds(const Source& src, int level, int len, size_t scratch) {
+    const size_t g = gather_lds(len, level, src.kind, src.ntaps, true);
+    const size_t alt = (size_t)2 * (len + 8) * sizeof(cplx) + scratch;
+    return ((g > alt ? g : alt) + 15) & ~(size_t)15;
 }
 
 int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, bool tiles, int nwin_grid,
@@ -240,6 +256,10 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
     c->tw_n = nfft;
     ++c->ws_epoch;
     return 0;
+}
+
+size_t burst_scratch(const Geom& g) {   // B[37][N2+1] | w37 (40) | wN2 | P[2*hnl <= 2*nfft/16]
+    return ((size_t)37 * (g.nfft / 37 + 1) + 40 + g.nfft / 37) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
 }
 
 size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
@@ -277,13 +297,13 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
            (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
            peaks, H, g.NB);
     LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
-    // bursts of the resampled (not yet derotated) stream: level lvl+1
-    RET_IF(launch_gather(c, S, src, lvl + 1, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
-           wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
-    const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
-    LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, (const cplx*)c->tw.p, g.ov, 1);
+    // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
+    // and SNR gate fused per burst
+    {
+        const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
+        LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
+               g.nfft, (const cplx*)c->tw.p, g.ov);
+    }
     if (next_sch_lvl >= 0)
         LAUNCH(c, k_step<STEP_CARRIER_DECIDE | STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_sch_lvl);
     else
@@ -302,10 +322,12 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
     cplx* win = (cplx*)c->cur->win.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
-    RET_IF(launch_gather(c, S, src, lvl, wl, false, H, win, sstride, wstride));
-    const size_t lds = (size_t)(wl + len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
-    LAUNCH(c, k_sch_corr, dim3(H, S), dim3(512), lds, st, (const cplx*)win, sstride, wstride,
-           (const cplx*)c->ts.p, len_ts, g.sch_nshift, 0);
+    {
+        const GatherArgs ga = gather_args(src, lvl, wl);
+        const size_t scratch = (size_t)(len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+        LAUNCH(c, k_window_sch, dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
+               len_ts, g.sch_nshift);
+    }
     if (next_post_lvl >= 0)
         LAUNCH(c, k_step<STEP_SCH_DECIDE | STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_post_lvl);
     else
@@ -328,12 +350,11 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     StepArgs sa = step_args(c, g, H, 0);
     sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
-    RET_IF(launch_gather(c, S, src, lvl, g.nfft, false, H, win, sstride, wstride));
-    LAUNCH(c, k_fft_burst<0>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
-           wstride, g.nfft, (const cplx*)c->tw.p, peaks, (cplx*)nullptr, H);
-    const size_t tone_lds = fft_lds(g) + (size_t)g.nfft * sizeof(double);
-    LAUNCH(c, k_tone, dim3(H, S), dim3(256), tone_lds, st, (const cplx*)win, sstride, wstride, g.nfft,
-           (const PeakOut*)peaks, H, (const cplx*)c->tw.p, g.ov, 0);
+    {
+        const GatherArgs ga = gather_args(src, lvl, g.nfft);
+        LAUNCH(c, k_burst_tone<0>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
+               g.nfft, (const cplx*)c->tw.p, g.ov);
+    }
     if (table)
         LAUNCH(c, k_step<STEP_POST_DECIDE | STEP_TOTALS>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     else
@@ -551,7 +572,9 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_tone, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     gsmcal_ctx* c = new gsmcal_ctx();

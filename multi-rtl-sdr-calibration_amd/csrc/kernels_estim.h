@@ -1,8 +1,8 @@
 // kernels_estim.h -- estimators on gathered windows and the per-stream decision kernels.
 //
-//   k_tone        tone-frequency estimator of FCCH_fine_correction.m:148-155 (+ SNR gate :185-189)
-//                 and carrier_correct_post_SCH.m:63-72, one workgroup per FCCH burst
-//   k_sch_corr    SCH_corr_rate_correction.m:50-55: |sch_ts' * window|^2 for the 89 offsets, argmax
+//   k_burst_tone  gather + spectrum argmax + tone-frequency estimator of FCCH_fine_correction.m:148-155
+//                 (+ SNR gate :185-189) and carrier_correct_post_SCH.m:63-72, one workgroup per burst
+//   k_window_sch  gather + SCH_corr_rate_correction.m:50-55: |sch_ts' * window|^2 for the 89 offsets
 //   k_*_setup / k_*_decide   the integer / ppm logic of the reference functions, one thread per
 //                 stream, writing the next stage's window list into StreamState
 #pragma once
@@ -23,50 +23,78 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tone: grid (H, S), block 256.  win: bursts of nfft samples.  peaks: spectrum argmax (one per burst).
-// Writes st->fo_burst[w] and (do_gate) st->snr_burst[w].
-// LDS: xs[nfft] | (gate) B[37][N2+1] | w37 | wN2 | P[nfft].
-// The SNR gate needs only the bins [0,hnl) and [nfft-hnl,nfft): step 1 of the 37 x N2 FFT in full,
-// step 2 for those bins only.
+// k_burst_tone<GATE>: one workgroup per FCCH burst does the whole per-burst estimate without leaving
+// LDS: gather the burst window at level a.level (raw -> raw2iq -> FIR -> lerp [-> mix -> lerp]),
+// 1184-point spectrum argmax in fftshift order, integer-bin derotation, unit-phasor phase step
+// (FCCH_fine_correction.m:148-155 / carrier_correct_post_SCH.m:63-72) and, for GATE, the SNR gate
+// (:185-189).  grid (H, S), block 512.  Writes st->fo_burst[w] and (GATE) st->snr_burst[w].
+// LDS: the gather carve (kernels_frontend.h); once the window is in buf0/buf1 the rest of the carve is
+// dead and is reused for B[37][N2+1] | w37 | wN2 | P[2*hnl].
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, const cplx* __restrict__ win,
-                                              long win_stream_stride, long win_stride, int nfft,
-                                              const PeakOut* __restrict__ peaks, int H,
-                                              const cplx* __restrict__ tw_g, int ov, int do_gate) {
+#define BT_THREADS 512
+template <int GATE>
+__global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft,
+                                                           const cplx* __restrict__ tw_g, int ov) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int N2 = nfft / 37, ldb = N2 + 1;
-    cplx* xs = (cplx*)smem;            // nfft derotated samples
-    cplx* B = xs + nfft;               // 37 * ldb   (gate only)
-    cplx* w37 = B + 37 * ldb;          // 37 (+3 pad)
-    cplx* wN2 = w37 + 40;              // N2
-    double* P = (double*)(wN2 + N2);   // nfft bin powers (only the gate's bins are filled)
-    __shared__ double red[8];
+    __shared__ double red_p[BT_THREADS / 64];
+    __shared__ int red_t[BT_THREADS / 64];
+    __shared__ double red[2 * (BT_THREADS / 64)];
     __shared__ double sh_phase;
-    const int s = blockIdx.y, w = blockIdx.x;
+    __shared__ int sh_key;
+    const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    cplx* xs = gather_core<BT_THREADS>(sts, a, smem, w, s, true);   // nfft samples of the burst, in LDS
+    if (!xs) return;                                                // block-uniform
+    __syncthreads();
     StreamState* st = sts + s;
-    if (w >= st->n_win) return;
-    const int tid = threadIdx.x;
-    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    const PeakOut pk = peaks[(size_t)s * H + w];
-    const int max_idx = pk.tie + 1;                                    // 1-based index after fftshift
+    const int N2 = nfft / 37, ldb = N2 + 1;
+    cplx* B = (cplx*)(smem + (size_t)2 * (a.len + 8) * sizeof(cplx));
+    cplx* w37 = B + 37 * ldb;
+    cplx* wN2 = w37 + 40;
+    double* P = (double*)(wN2 + N2);
+    fft37_tables(w37, wN2, N2, tid);
+    __syncthreads();
+    // ---- spectrum argmax, first max in fftshift order (:149-150) ----
+    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
+    __syncthreads();
+    double best = -1.0;
+    int key = 0x7fffffff;
+    for (int k = tid; k < nfft; k += BT_THREADS) {
+        const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
+        const double p = X.x * X.x + X.y * X.y;
+        const int sk = (k + nfft / 2) % nfft;
+        if (p > best || (p == best && sk < key)) { best = p; key = sk; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double op = __shfl_down(best, off, 64);
+        const int ok = __shfl_down(key, off, 64);
+        if (op > best || (op == best && ok < key)) { best = op; key = ok; }
+    }
+    if ((tid & 63) == 0) { red_p[tid >> 6] = best; red_t[tid >> 6] = key; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < BT_THREADS / 64; ++i)
+            if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; }
+        sh_key = key;
+    }
+    __syncthreads();
+    const int max_idx = sh_key + 1;                                    // 1-based index after fftshift
     const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
     // :151  int_phase_rotate = 2.*pi.*(max_idx - ((fft_len/2)+1))./fft_len
     const double ipr = (TWO_PI_D * (double)(max_idx - (nfft / 2 + 1))) / (double)nfft;
-    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)
-    for (int n = tid; n < nfft; n += 256) {
+    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)   (in place)
+    for (int n = tid; n < nfft; n += BT_THREADS) {
         double sn, cs;
         sincos((double)n * ipr, &sn, &cs);
-        xs[n] = cmul(x[n], make_double2(cs, -sn));
+        xs[n] = cmul(xs[n], make_double2(cs, -sn));
     }
-    if (do_gate) fft37_tables(w37, wN2, N2, tid);
     __syncthreads();
     // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) )
     double sr = 0.0, si = 0.0;
-    for (int n = tid; n < nfft - 1; n += 256) {
-        const cplx a = xs[n + 1], b = xs[n];
-        const double ma = hypot(a.x, a.y), mb = hypot(b.x, b.y);
-        const cplx ua = ma > 0.0 ? make_double2(a.x / ma, a.y / ma) : make_double2(1.0, 0.0);
-        const cplx ub = mb > 0.0 ? make_double2(b.x / mb, b.y / mb) : make_double2(1.0, 0.0);
+    for (int n = tid; n < nfft - 1; n += BT_THREADS) {
+        const cplx p1 = xs[n + 1], p0 = xs[n];
+        const double ma = hypot(p1.x, p1.y), mb = hypot(p0.x, p0.y);
+        const cplx ua = ma > 0.0 ? make_double2(p1.x / ma, p1.y / ma) : make_double2(1.0, 0.0);
+        const cplx ub = mb > 0.0 ? make_double2(p0.x / mb, p0.y / mb) : make_double2(1.0, 0.0);
         const double den = ub.x * ub.x + ub.y * ub.y;
         sr += (ua.x * ub.x + ua.y * ub.y) / den;
         si += (ua.y * ub.x - ua.x * ub.y) / den;
@@ -79,66 +107,62 @@ __global__ void __launch_bounds__(256) k_tone(StreamState* __restrict__ sts, con
     __syncthreads();
     if (tid == 0) {
         double tr = 0.0, ti = 0.0;
-        for (int i = 0; i < 4; ++i) { tr += red[2 * i]; ti += red[2 * i + 1]; }
+        for (int i = 0; i < BT_THREADS / 64; ++i) { tr += red[2 * i]; ti += red[2 * i + 1]; }
         const double cnt = (double)(nfft - 1);
         const double phase = atan2(ti / cnt, tr / cnt);
         sh_phase = phase;
         st->fo_burst[w] = sampling_rate * (ipr + phase) / TWO_PI_D;   // :155
     }
-    if (!do_gate) return;
+    if (!GATE) return;
     __syncthreads();
-    // ---- SNR gate, FCCH_fine_correction.m:185-189 ----
+    // ---- SNR gate, FCCH_fine_correction.m:185-189: bins [0,hnl) and [nfft-hnl,nfft) only ----
     const double phase = sh_phase;
-    for (int n = tid; n < nfft; n += 256) {
+    for (int n = tid; n < nfft; n += BT_THREADS) {
         double sn, cs;
         sincos((double)n * phase, &sn, &cs);
-        const cplx v = xs[n];                       // each n is owned by exactly one thread
-        xs[n] = cmul(v, make_double2(cs, -sn));
+        xs[n] = cmul(xs[n], make_double2(cs, -sn));
     }
     __syncthreads();
-    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, 256);
+    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
     __syncthreads();
     const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
-    const int nb = 2 * hnl;                         // bins needed: [0, hnl) and [nfft-hnl, nfft)
-    for (int b = tid; b < nb; b += 256) {
+    const int nb = 2 * hnl;
+    for (int b = tid; b < nb; b += BT_THREADS) {
         const int k = b < hnl ? b : nfft - nb + b;
         const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
         const double m = hypot(X.x, X.y);
-        P[k] = m * m;
+        P[b] = m * m;                               // P[b]: b < hnl -> bin b; else bin nfft-nb+b
     }
     __syncthreads();
     if (tid == 0) {
         // signal: fd([1:3, end-1:end]); noise: fd([4:hnl, end-hnl+1:end-2])   (1-based)
         double sig = 0.0, noi = 0.0;
         for (int k = 0; k < 3; ++k) sig += P[k];
-        for (int k = nfft - 2; k < nfft; ++k) sig += P[k];
+        for (int k = nb - 2; k < nb; ++k) sig += P[k];
         for (int k = 3; k < hnl; ++k) noi += P[k];
-        for (int k = nfft - hnl; k < nfft - 2; ++k) noi += P[k];
+        for (int k = hnl; k < nb - 2; ++k) noi += P[k];
         st->snr_burst[w] = 10.0 * log10(sig / noi);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sch_corr: grid (H, S), block 512.  window length nshift-1+len_ts; ts = sch_training_sequence.
-// Each of the nshift offsets is summed by 4 lanes (quarters of the template) and combined.
-// Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge.
+// k_window_sch: one workgroup per FCCH gathers its SCH search window (nshift-1+len_ts samples at
+// level a.level) into LDS and correlates it with the training sequence at the nshift offsets
+// (SCH_corr_rate_correction.m:45-55); 4 lanes per offset.  grid (H, S), block 512.
+// Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge (:59).
 // ------------------------------------------------------------------------------------------------
 #define SCH_PARTS 4
-__global__ void __launch_bounds__(512) k_sch_corr(StreamState* __restrict__ sts, const cplx* __restrict__ win,
-                                                  long win_stream_stride, long win_stride,
-                                                  const cplx* __restrict__ ts, int len_ts, int nshift, int unused_) {
+__global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
+                                                    const cplx* __restrict__ ts, int len_ts, int nshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* xs = (cplx*)smem;                 // window
-    cplx* tc = xs + (nshift - 1 + len_ts);  // conj(ts)
-    cplx* part = tc + len_ts;               // nshift * SCH_PARTS partial sums
-    double* cv = (double*)(part + nshift * SCH_PARTS);   // nshift correlation powers
-    const int s = blockIdx.y, w = blockIdx.x;
+    const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
+    if (!xs) return;
+    cplx* tc = (cplx*)(smem + (size_t)2 * (a.len + 8) * sizeof(cplx));   // conj(ts)
+    cplx* part = tc + len_ts;                                             // nshift * SCH_PARTS partial sums
+    double* cv = (double*)(part + nshift * SCH_PARTS);                    // nshift correlation powers
+    __syncthreads();
     StreamState* st = sts + s;
-    if (w >= st->n_win) return;
-    const int tid = threadIdx.x;
-    const int wl = nshift - 1 + len_ts;
-    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    for (int i = tid; i < wl; i += 512) xs[i] = x[i];
     for (int i = tid; i < len_ts; i += 512) tc[i] = make_double2(ts[i].x, -ts[i].y);
     __syncthreads();
     const int seg = (len_ts + SCH_PARTS - 1) / SCH_PARTS;
@@ -170,7 +194,6 @@ __global__ void __launch_bounds__(512) k_sch_corr(StreamState* __restrict__ sts,
         st->sch_first[w] = (double)(st->win_start[w] + 1 + mi);   // sp + max_idx - 1
         if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
     }
-    (void)unused_;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -225,32 +225,37 @@ __device__ __forceinline__ long level_len(const StreamState* st, int level) {
 // samples 4 apart (the 4-outputs-per-lane FIR below) hit distinct banks with ds_read_b128.
 __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 
-__global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// gather_core<NT>: the body shared by k_gather and the fused per-window kernels (kernels_estim.h).
+// to_lds = false: the window is written to global memory (a.dst).  to_lds = true: the last level
+// stays in LDS and its address is returned (nullptr if this block has no window).
+// The block's window index is `widx`, its stream `s`.  smem: the dynamic LDS base, carved as
+//   buf0 | buf1 | coef | raw ushorts | xs (padded complex input)          (host: gather_lds()).
+template <int NT>
+__device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts, const GatherArgs& a,
+                                             unsigned char* smem, int widx, int s, bool to_lds) {
     // LDS carve (host: gather_lds): buf0 | buf1 | coef | raw ushorts | xs (padded complex input)
-    const int bufn = a.level >= 1 ? a.len + 8 : 0;
+    const int bufn = (a.level >= 1 || to_lds) ? a.len + 8 : 0;     // to_lds: always two buffers
     cplx* buf0 = (cplx*)smem;
     cplx* buf1 = buf0 + bufn;
-    double* c_s = (double*)(buf1 + (a.level >= 2 ? bufn : 0));
+    double* c_s = (double*)(buf1 + ((a.level >= 2 || to_lds) ? bufn : 0));
     unsigned short* r_s = (unsigned short*)(c_s + ((a.ntaps + 1) & ~1));
     const int span_max = a.len + 8 + a.ntaps + 24;
     cplx* xs = (cplx*)(r_s + ((span_max + 7) & ~7));
-    const int s = blockIdx.y;
     const StreamState* st = sts + s;
     const int level = a.level;
     long start, L;
     cplx* dst;
     if (a.tiles) {
         const long nq = level_len(st, level);
-        start = (long)blockIdx.x * a.len;
-        if (start >= nq) return;
+        start = (long)widx * a.len;
+        if (start >= nq) return nullptr;
         L = nq - start < a.len ? nq - start : a.len;
         dst = a.dst + (size_t)s * a.dst_stream_stride + start;
     } else {
-        if ((int)blockIdx.x >= st->n_win) return;
-        start = st->win_start[blockIdx.x];
+        if (widx >= st->n_win) return nullptr;
+        start = st->win_start[widx];
         L = a.len;
-        dst = a.dst + (size_t)s * a.dst_stream_stride + (size_t)blockIdx.x * a.dst_win_stride;
+        dst = a.dst + (size_t)s * a.dst_stream_stride + (size_t)widx * a.dst_win_stride;
     }
     // backward range propagation
     long lo[NLEVELS], hi[NLEVELS];
@@ -271,12 +276,12 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
     // ---- level 0 ----
     const long lo0 = lo[0], hi0 = hi[0];
     const int cnt0 = (int)(hi0 - lo0 + 1);
-    cplx* out0 = (level == 0) ? dst : buf0;
+    cplx* out0 = (level == 0 && !to_lds) ? dst : buf0;
     const int tid = threadIdx.x;
     if (a.src_kind == SRC_ARR) {
         const cplx* x = a.arr + (size_t)s * a.arr_stride;
         const long n0 = st->n0;
-        for (int i = tid; i < cnt0; i += 256) {
+        for (int i = tid; i < cnt0; i += NT) {
             const long g = lo0 + i;
             out0[i] = (g >= 0 && g < n0) ? x[g] : make_double2(0.0, 0.0);
         }
@@ -286,14 +291,14 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
         const int ntp = a.ntaps;
         const long first = lo0 - (ntp - 1);
         const int span = cnt0 + ntp - 1;
-        for (int i = tid; i < ntp; i += 256) c_s[i] = a.coef[i];
-        const long first_al = stage_raw(r_s, base, n0, first, span, tid, 256);
+        for (int i = tid; i < ntp; i += NT) c_s[i] = a.coef[i];
+        const long first_al = stage_raw(r_s, base, n0, first, span, tid, NT);
         __syncthreads();
         // raw2iq.m:6-8 on the staged span: (I - mean) + 1i (Q - mean); zero before the stream starts
         // (filter()'s zero initial state) and past its end
         const double mr = st->mean_re, mi = st->mean_im;
         const int off = (int)(first - first_al);
-        for (int i = tid; i < span + 8; i += 256) {
+        for (int i = tid; i < span + 8; i += NT) {
             const long g = first + i;
             cplx v = make_double2(0.0, 0.0);
             if (i < span && g >= 0 && g < n0) {
@@ -305,7 +310,7 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
         __syncthreads();
         // filter(coef,1,.) : y[i] = sum_k coef[k] x[i-k], accumulated oldest tap first (transposed
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
-        for (int i0 = 4 * tid; i0 < cnt0; i0 += 1024) {
+        for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
             double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
             cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
             int p = i0 + 3;
@@ -330,13 +335,13 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
     cplx* other = buf1;
     for (int j = 1; j <= level; ++j) {
         __syncthreads();
-        cplx* o = (j == level) ? dst : other;
+        cplx* o = (j == level && !to_lds) ? dst : other;
         const int cnt = (int)(hi[j] - lo[j] + 1);
         const int type = st->op[j].type;
         const double p = st->op[j].param;
         const long plo = lo[j - 1], phi_ = hi[j - 1];
         if (type == OP_LERP) {
-            for (int i = threadIdx.x; i < cnt; i += 256) {
+            for (int i = threadIdx.x; i < cnt; i += NT) {
                 const long k = lo[j] + i;
                 const double xq = (double)k * p;            // interp_seq = (0:max_len-1)'.*(1+e)
                 const long i0 = (long)floor(xq);
@@ -346,16 +351,22 @@ __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ 
                 o[i] = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
             }
         } else if (type == OP_MIX) {
-            for (int i = threadIdx.x; i < cnt; i += 256) {
+            for (int i = threadIdx.x; i < cnt; i += NT) {
                 const long k = lo[j] + i;
                 double sn, cs;
                 sincos((double)k * p, &sn, &cs);            // exp(1i*(0:len-1)'*comp_phase_rotate)
                 o[i] = cmul(src[i], make_double2(cs, sn));
             }
         } else {
-            for (int i = threadIdx.x; i < cnt; i += 256) o[i] = src[i];
+            for (int i = threadIdx.x; i < cnt; i += NT) o[i] = src[i];
         }
         cplx* tmp = src; src = other; other = tmp;
         (void)tmp;
     }
+    return to_lds ? src : nullptr;   // after the last swap `src` is the buffer written last
+}
+
+__global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    (void)gather_core<256>(sts, a, smem, blockIdx.x, blockIdx.y, false);
 }
