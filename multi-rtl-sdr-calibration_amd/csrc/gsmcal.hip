@@ -418,8 +418,18 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
+    if (getenv("GSMCAL_DBG_COARSE")) { RET_IF(ensure(c, c->misc, (size_t)S * 64 + 1024)); a.dbg = (unsigned long long*)c->misc.p; }
     LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
     LAUNCH(c, k_coarse_scan, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    if (a.dbg) {
+        std::vector<unsigned long long> h((size_t)S * 8);
+        (void)hipStreamSynchronize(c->cur->stream);
+        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < S && i < 64; ++i)
+            fprintf(stderr, "coarse[%d] load %.1f scan %.1f hops %.1f setup %.1f store %.1f us hit %llu n %llu\n", i,
+                    (h[i*8+1]-h[i*8+0]) / 100.0, (h[i*8+2]-h[i*8+1]) / 100.0, (h[i*8+3]-h[i*8+2]) / 100.0,
+                    (h[i*8+4]-h[i*8+3]) / 100.0, (h[i*8+5]-h[i*8+4]) / 100.0, h[i*8+6], h[i*8+7]);
+    }
     CHECK_LAUNCH(c);
     return 0;
 }

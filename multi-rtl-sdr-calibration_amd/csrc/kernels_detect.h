@@ -76,10 +76,7 @@ __device__ __forceinline__ double window_snr16(const cplx* __restrict__ s) {
     fft16(x);
     double P[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const double m = hypot(x[i].x, x[i].y);  // abs(fft(.)).^2
-        P[i] = m * m;
-    }
+    for (int i = 0; i < 16; ++i) P[i] = x[i].x * x[i].x + x[i].y * x[i].y;   // abs(fft(.)).^2
     return snr_from_power<16>(P);
 }
 
@@ -126,6 +123,7 @@ struct CoarseArgs {
     long t_lo, t_hi; double avg_snr;          // mode 2: target_set and fixed average
     double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
     int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
+    unsigned long long* dbg;                  // optional: 8 timestamps per stream (development aid)
 };
 
 struct CoarseGeom { int fft_len, mv_len; double th; long n_first, nwin; };
@@ -194,6 +192,8 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     const int fft_len = g.fft_len, mv_len = g.mv_len;
     const double th = g.th;
     const int tid = threadIdx.x;
+#define CS_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    CS_STAMP(0);
     {
         const uint4* src = (const uint4*)st_g;
         uint4* dst = (uint4*)st;
@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     }
     __syncthreads();
     int n = 0;
+    CS_STAMP(1);
     if (!bad && a.mode != 2) {
         // ---- move_fft_snr_runtime_avg ----
         const long nwin = g.nwin;
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
             }
         }
         __syncthreads();
+        CS_STAMP(2);
         const int hit = sh_hit;
         if (hit != 0x7fffffff && tid == 0) {
             const double h_snr = snr_s[mv_len + hit];
@@ -289,36 +291,40 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
                     st->coarse_pos[0] = (double)((cur - 1) * dec + 1);  // :91
                     st->coarse_snr[0] = st->mv_hit_snr;
                 }
+                // wave 0 only, no barriers: lanes 0..10 evaluate the +10-frame candidates, lanes 11..21 the
+                // +11-frame ones (consulted only when the former all miss); ballots keep everything uniform
                 const int nt = 2 * max_offset + 1;
-                double* hop = snr_s;                                     // the scan is over: reuse
-                while (n < MAXH) {
-                    const long nx0 = cur + d0, nx1 = cur + d1;
-                    if (nx0 > limit) break;                              // :49
-                    __syncthreads();
-                    if (tid < nt) hop[tid] = window_snr(s + (nx0 - max_offset - 1 + tid), fft_len, tw);
-                    else if (tid < 2 * nt && nx1 <= limit)
-                        hop[tid] = window_snr(s + (nx1 - max_offset - 1 + (tid - nt)), fft_len, tw);
-                    __syncthreads();
-                    int found = -1;
-                    long nxt = nx0;
-                    for (int i = 0; i < nt; ++i)                         // every thread scans: uniform result
-                        if (hop[i] - hit_avg_snr > th) { found = i; break; }
-                    if (found < 0) {
-                        if (nx1 > limit) break;                          // :67
-                        nxt = nx1;                                       // :65 across the idle frame
-                        for (int i = 0; i < nt; ++i)
-                            if (hop[nt + i] - hit_avg_snr > th) { found = nt + i; break; }
-                        if (found < 0) break;
+                if (tid < 64) {
+                    const int lane = tid;
+                    while (n < MAXH) {
+                        const long nx0 = cur + d0, nx1 = cur + d1;
+                        if (nx0 > limit) break;                              // :49
+                        double v = -INFINITY;
+                        if (lane < nt) v = window_snr(s + (nx0 - max_offset - 1 + lane), fft_len, tw);
+                        else if (lane < 2 * nt && nx1 <= limit)
+                            v = window_snr(s + (nx1 - max_offset - 1 + (lane - nt)), fft_len, tw);
+                        const unsigned long long hits = __ballot(v - hit_avg_snr > th);   // NaN / -inf compare false
+                        const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
+                        int found;
+                        long nxt;
+                        if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; }
+                        else {
+                            if (nx1 > limit) break;                          // :67
+                            if (!h1) break;
+                            found = nt + __ffsll((long long)h1) - 1;         // :65 across the idle frame
+                            nxt = nx1;
+                        }
+                        const double fsnr = __shfl(v, found, 64);
+                        cur = nxt - max_offset + (found >= nt ? found - nt : found);
+                        if (lane == 0) {
+                            st->coarse_pos[n] = (double)((cur - 1) * dec + 1);
+                            st->coarse_snr[n] = fsnr;
+                        }
+                        ++n;
                     }
-                    const double fsnr = hop[found];
-                    cur = nxt - max_offset + (found >= nt ? found - nt : found);
-                    if (tid == 0) {
-                        st->coarse_pos[n] = (double)((cur - 1) * dec + 1);
-                        st->coarse_snr[n] = fsnr;
-                    }
-                    ++n;
                 }
                 if (tid == 0) st->n_coarse = n;
+                CS_STAMP(3);
             }
         }
     } else if (!bad) {
@@ -346,11 +352,14 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     __syncthreads();
     if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0);
     __syncthreads();
+    CS_STAMP(4);
     {
         const uint4* src = (const uint4*)st;
         uint4* dst = (uint4*)st_g;
         for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
     }
+    CS_STAMP(5);
+    if (a.dbg && tid == 0) { a.dbg[blockIdx.x * 8 + 6] = (unsigned long long)sh_hit; a.dbg[blockIdx.x * 8 + 7] = (unsigned long long)n; }
 }
 
 // ------------------------------------------------------------------------------------------------
