@@ -69,8 +69,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # one process per GPU; the collective runs whenever a process group exists (GSMCAL_FORCE_DIST=1 lets a
+    # single-rank torchrun exercise the RCCL path on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("GSMCAL_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     D, frames = args.streams, args.frames
@@ -89,7 +93,7 @@ def main():
     pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
     rlen_t = torch.zeros((D,), dtype=torch.int64, device=dev)
     r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if args.mode == "stream" else None
-    gathered = torch.zeros((world * D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) if use_dist else None
 
     # a dedicated (non-default) stream: the library forks its internal lanes off this stream, and torch's
     # collectives are enqueued on it too, so one synchronize covers the whole step
@@ -107,12 +111,12 @@ def main():
                                             C.c_void_p(r_t.data_ptr()) if r_t is not None else None,
                                             C.c_void_p(rlen_t.data_ptr()))
         ctx.check(rc, "gsmcal_calibrate_batch_dev")
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, table_t)   # one RCCL all-gather of the per-dongle ppm table
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -145,9 +149,9 @@ def main():
         torch.cuda.synchronize(dev)
         prof = ctx.profile_get()
         ctx.profile_enable(False)
-    if world > 1:
+    if use_dist:
         fence()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -170,7 +174,7 @@ def main():
                                f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation",
                    "streams_per_gpu": D, "samples_per_stream": N, "output": args.mode,
                    "bytes_per_sample_algorithmic": 2 if args.mode == "table" else 18,
-                   "collective": "all_gather(table) over RCCL" if world > 1 else "none",
+                   "collective": "all_gather(table) over RCCL" if use_dist else "none",
                    "streams_calibrated_ok": n_ok},
     }
 
@@ -235,7 +239,9 @@ def main():
             out["parity_checked_streams"] = checked
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gathered is not None:
+            assert torch.equal(gathered[:D], table_t), "all-gathered table differs from the local rows"
         dist.destroy_process_group()
 
 

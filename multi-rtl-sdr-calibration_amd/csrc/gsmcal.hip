@@ -395,6 +395,20 @@ int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const doub
     return 0;
 }
 
+// batch front end: one pass over the raw bytes (sums + FIR of the raw samples), then the means
+int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
+                cplx* d_out, long out_stride) {
+    const long nd = (n + decim - 1) / decim;
+    const size_t span = (size_t)256 * decim + ntaps + 24;
+    const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
+    if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
+    LAUNCH(c, k_front_fused, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
+           (StreamState*)c->cur->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
+    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->cur->state.p, S, n);
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
 int hits_capacity(long len_dec, int dec_ratio) {
     // FCCH_coarse_position.m:38 max_num_fcch = ceil(len/(10*num_sym_per_frame/decimation_ratio))
     int h = (int)ceil((double)len_dec / (12500.0 / (double)dec_ratio));
@@ -406,9 +420,18 @@ size_t coarse_scan_lds(long nwin, int mv_len) {
     return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + (size_t)(nwin + mv_len + 128) * sizeof(double);
 }
 
-int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov) {
+int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
+           bool mean_corr = false) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
+    if (mean_corr) {   // input = FIR of the raw bytes (front_fused): DC removed on load
+        a.mean_corr = 1;
+        a.sts_mean = (const StreamState*)c->cur->state.p;
+        double cs = 0.0;
+        for (double v : c->h_coef) cs += v;
+        a.csum_all = cs;
+        a.csum_first = c->h_coef.empty() ? 0.0 : c->h_coef[0];
+    }
     a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
     a.fine_setup_ov = fine_setup_ov;
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
@@ -581,6 +604,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     // kernels whose dynamic LDS may exceed the 64 KiB default
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -1050,9 +1074,8 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
         RET_IF(init_states(c, S, n));
-        RET_IF(dc_means(c, raw_i, S, n));
-        RET_IF(fir_decim_raw(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0));
+        RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
@@ -1126,9 +1149,8 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
         RET_IF(init_states(c, S, n));
-        RET_IF(dc_means(c, raw_i, S, n));                                                   // raw2iq.m:8
-        RET_IF(fir_decim_raw(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov));                  // :117 (+ fine window setup)
+        RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true));            // :117 (+ fine window setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;
         RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts));                              // :118 (+ SCH window setup)

@@ -69,10 +69,24 @@ __device__ __forceinline__ double snr_from_power(const double (&P)[L]) {
     return 10.0 * log10(sig / noise);
 }
 
-__device__ __forceinline__ double window_snr16(const cplx* __restrict__ s) {
+// The decimated detector input.  In the batch path the fused front end (k_front_fused) stores the FIR
+// of the RAW bytes, y'[j] = sum_k coef[k]*raw[64j-k]; the DC term is removed here on load by linearity:
+// y[j] = y'[j] - mean * sum_{valid k} coef[k]  (all taps for j >= 1, tap 0 only for j = 0).
+// With corr == 0 the view is a plain array (API paths, exact reference operation order).
+struct DecView {
+    const cplx* s;
+    double cr, ci;      // mean * sum(coef)        (subtracted from every sample j >= 1)
+    double c0r, c0i;    // mean * coef[0]          (sample 0: zero initial state)
+};
+__device__ __forceinline__ cplx dv_load(const DecView& v, long j) {
+    const cplx x = v.s[j];
+    return j == 0 ? make_double2(x.x - v.c0r, x.y - v.c0i) : make_double2(x.x - v.cr, x.y - v.ci);
+}
+
+__device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     cplx x[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = s[i];
+    for (int i = 0; i < 16; ++i) x[i] = dv_load(v, start + i);
     fft16(x);
     double P[16];
 #pragma unroll
@@ -82,13 +96,14 @@ __device__ __forceinline__ double window_snr16(const cplx* __restrict__ s) {
 
 // generic length (2..64) via direct DFT with tw[m] = exp(-2*pi*i*m/L); nothing is stored: the bins
 // around the first max are recomputed (bit-identical) after the scan.
-__device__ __forceinline__ double dft_bin_power(const cplx* __restrict__ s, int fft_len, const cplx* tw, int k) {
+__device__ __forceinline__ double dft_bin_power(const DecView& v, long start, int fft_len, const cplx* tw, int k) {
     double ar = 0.0, ai = 0.0;
     int idx = 0;
     for (int n = 0; n < fft_len; ++n) {
         const cplx w = tw[idx];
-        ar += s[n].x * w.x - s[n].y * w.y;
-        ai += s[n].x * w.y + s[n].y * w.x;
+        const cplx x = dv_load(v, start + n);
+        ar += x.x * w.x - x.y * w.y;
+        ai += x.x * w.y + x.y * w.x;
         idx += k;
         if (idx >= fft_len) idx -= fft_len;
     }
@@ -96,23 +111,23 @@ __device__ __forceinline__ double dft_bin_power(const cplx* __restrict__ s, int 
     return m * m;
 }
 
-__device__ __noinline__ double window_snr_generic(const cplx* __restrict__ s, int fft_len, const cplx* tw) {
+__device__ __noinline__ double window_snr_generic(const DecView& s, long start, int fft_len, const cplx* tw) {
     int mi = 0;
     double mx = -1.0, tot = 0.0;
     for (int k = 0; k < fft_len; ++k) {
-        const double p = dft_bin_power(s, fft_len, tw, k);
+        const double p = dft_bin_power(s, start, fft_len, tw, k);
         tot += p;
         if (p > mx) { mx = p; mi = k; }             // first max
     }
     const int km = mi == 0 ? fft_len - 1 : mi - 1, kp = mi == fft_len - 1 ? 0 : mi + 1;
-    double sig = dft_bin_power(s, fft_len, tw, km) + mx;
-    sig = sig + dft_bin_power(s, fft_len, tw, kp);
+    double sig = dft_bin_power(s, start, fft_len, tw, km) + mx;
+    sig = sig + dft_bin_power(s, start, fft_len, tw, kp);
     const double noise = tot - sig;
     return 10.0 * log10(sig / noise);
 }
 
-__device__ __forceinline__ double window_snr(const cplx* __restrict__ s, int fft_len, const cplx* tw) {
-    return fft_len == 16 ? window_snr16(s) : window_snr_generic(s, fft_len, tw);
+__device__ __forceinline__ double window_snr(const DecView& s, long start, int fft_len, const cplx* tw) {
+    return fft_len == 16 ? window_snr16(s, start) : window_snr_generic(s, start, fft_len, tw);
 }
 
 struct CoarseArgs {
@@ -124,7 +139,19 @@ struct CoarseArgs {
     double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
     int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
     unsigned long long* dbg;                  // optional: 8 timestamps per stream (development aid)
+    double csum_all, csum_first;              // > 0 taps: the input is the FIR of the raw bytes; remove mean*csum on load
+    int mean_corr;
+    const StreamState* sts_mean;              // per-stream means (k_coarse_snr has no other use for the state)
 };
+
+__device__ __forceinline__ DecView dec_view(const CoarseArgs& a, int stream, double mean_re, double mean_im) {
+    DecView v;
+    v.s = a.s + (size_t)stream * a.s_stride;
+    const double m = a.mean_corr ? 1.0 : 0.0;
+    v.cr = m * mean_re * a.csum_all;   v.ci = m * mean_im * a.csum_all;
+    v.c0r = m * mean_re * a.csum_first; v.c0i = m * mean_im * a.csum_first;
+    return v;
+}
 
 struct CoarseGeom { int fft_len, mv_len; double th; long n_first, nwin; };
 
@@ -162,8 +189,9 @@ __global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.nwin) return;
-    const cplx* s = a.s + (size_t)blockIdx.y * a.s_stride;
-    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s + i, g.fft_len, tw);
+    const DecView s = a.mean_corr ? dec_view(a, blockIdx.y, a.sts_mean[blockIdx.y].mean_re, a.sts_mean[blockIdx.y].mean_im)
+                                  : dec_view(a, blockIdx.y, 0.0, 0.0);
+    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s, i, g.fft_len, tw);
 }
 
 __device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl);   // kernels_estim.h
@@ -186,7 +214,7 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
     double* snr_s = (double*)(tw + 64);
     StreamState* st_g = sts + blockIdx.x;
-    const cplx* s = a.s + (size_t)blockIdx.x * a.s_stride;
+    const DecView s = dec_view(a, blockIdx.x, st_g->mean_re, st_g->mean_im);
     const long len = a.len;
     const CoarseGeom g = coarse_geom(a);
     const int fft_len = g.fft_len, mv_len = g.mv_len;
@@ -300,9 +328,9 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
                         const long nx0 = cur + d0, nx1 = cur + d1;
                         if (nx0 > limit) break;                              // :49
                         double v = -INFINITY;
-                        if (lane < nt) v = window_snr(s + (nx0 - max_offset - 1 + lane), fft_len, tw);
+                        if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
                         else if (lane < 2 * nt && nx1 <= limit)
-                            v = window_snr(s + (nx1 - max_offset - 1 + (lane - nt)), fft_len, tw);
+                            v = window_snr(s, nx1 - max_offset - 1 + (lane - nt), fft_len, tw);
                         const unsigned long long hits = __ballot(v - hit_avg_snr > th);   // NaN / -inf compare false
                         const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
                         int found;
@@ -335,7 +363,7 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
                 if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
             } else {
                 const long cnt = hi - lo + 1;
-                for (long i = tid; i < cnt; i += 256) snr_s[i] = window_snr(s + (lo - 1 + i), fft_len, tw);
+                for (long i = tid; i < cnt; i += 256) snr_s[i] = window_snr(s, lo - 1 + i, fft_len, tw);
                 __syncthreads();
                 if (tid == 0) {
                     for (long i = 0; i < cnt; ++i)

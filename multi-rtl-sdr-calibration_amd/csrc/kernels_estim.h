@@ -88,13 +88,18 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
         xs[n] = cmul(xs[n], make_double2(cs, -sn));
     }
     __syncthreads();
-    // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) )
+    // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) ): unit phasors u[n] = x/|x| once
+    // per sample (into the dead B region), then the complex quotients u[n+1]/u[n]
+    cplx* u = B;
+    for (int n = tid; n < nfft; n += BT_THREADS) {
+        const cplx p0 = xs[n];
+        const double m = hypot(p0.x, p0.y);
+        u[n] = m > 0.0 ? make_double2(p0.x / m, p0.y / m) : make_double2(1.0, 0.0);   // angle(0) = 0
+    }
+    __syncthreads();
     double sr = 0.0, si = 0.0;
     for (int n = tid; n < nfft - 1; n += BT_THREADS) {
-        const cplx p1 = xs[n + 1], p0 = xs[n];
-        const double ma = hypot(p1.x, p1.y), mb = hypot(p0.x, p0.y);
-        const cplx ua = ma > 0.0 ? make_double2(p1.x / ma, p1.y / ma) : make_double2(1.0, 0.0);
-        const cplx ub = mb > 0.0 ? make_double2(p0.x / mb, p0.y / mb) : make_double2(1.0, 0.0);
+        const cplx ua = u[n + 1], ub = u[n];
         const double den = ub.x * ub.x + ub.y * ub.y;
         sr += (ua.x * ub.x + ua.y * ub.y) / den;
         si += (ua.y * ub.x - ua.x * ub.y) / den;
@@ -230,11 +235,8 @@ __device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl) {
 __device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int H, int NB, int ov, int lvl) {
     (void)s;
     if (st->status < 0 || st->stage_status[0] != 0) { st->n_win = 0; return; }
-    const int last_idx = st->n_win;
-    for (int w = 0; w < last_idx; ++w) {
-        const PeakOut pk = merge_peaks(peaks + ((size_t)s * H + w) * NB, NB);
-        st->fine_first[w] = (double)(st->win_start[w] + 1 + pk.tie);          // sp + max_idx - 1
-    }
+    const int last_idx = st->n_win;        // fine_first[0..last_idx) was filled by the lanes of k_step
+    (void)peaks; (void)H; (void)NB;
     st->n_fine = last_idx;
     st->n_win = 0;
     const int fft_len = 148 * ov;
@@ -572,6 +574,12 @@ __global__ void __launch_bounds__(64) k_step(StreamState* __restrict__ sts, Step
     const int s = blockIdx.x, lane = threadIdx.x;
     StateLds::load(&sh, sts + s, lane);
     __syncthreads();
+    if ((STEPS & STEP_FINE_DECIDE) && lane < sh.n_win && lane < MAXH) {
+        // merge the NB partial peaks of window `lane` (the loads of all windows are in flight together)
+        const PeakOut pk = merge_peaks(a.peaks + ((size_t)s * a.H + lane) * a.NB, a.NB);
+        sh.fine_first[lane] = (double)(sh.win_start[lane] + 1 + pk.tie);          // sp + max_idx - 1
+    }
+    if (STEPS & STEP_FINE_DECIDE) __syncthreads();
     if (lane == 0) {
         if (STEPS & STEP_FINE_SETUP) d_fine_setup(&sh, s, a.ov, lvl_a);
         if (STEPS & STEP_FINE_DECIDE) d_fine_decide(&sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);

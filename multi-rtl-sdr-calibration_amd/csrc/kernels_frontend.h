@@ -182,6 +182,120 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_front_fused: ONE pass over the raw bytes for the batch paths.  Per block of 256 kept rows it
+//   (1) adds the bytes of its own decim*256 samples to the stream's exact integer I/Q sums (raw2iq.m:8),
+//   (2) writes y'[j] = sum_k coef[k]*raw[j*decim-k] for its rows -- the FIR of the RAW samples.
+// The detector subtracts mean*sum(coef) on load (DecView in kernels_detect.h): filter() is linear, so
+// y = y' - mean*sum_{valid k} coef[k]; this differs from filtering (raw-mean) only in fp64 rounding
+// (~1e-15 relative) and feeds nothing but the FCCH coarse detector's threshold decisions.
+// grid (ceil(nd/256), S), block 256.  LDS as k_fir_decim_raw.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__ raw, long stream_bytes,
+                                                     StreamState* __restrict__ st,
+                                                     const double* __restrict__ coef, int ntaps,
+                                                     int decim, long nd, cplx* __restrict__ out,
+                                                     long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* c_s = (double*)smem;
+    unsigned short* r_s = (unsigned short*)(smem + ((ntaps * 8 + 15) & ~15));
+    const int s = blockIdx.y;
+    const long n = stream_bytes >> 1;
+    const unsigned short* base = (const unsigned short*)(raw + (size_t)s * stream_bytes);
+    const long j0 = (long)blockIdx.x * 256;
+    if (j0 >= nd) return;
+    long jn = nd - j0;
+    if (jn > 256) jn = 256;
+    const long first = j0 * decim - (ntaps - 1);
+    // this block owns samples [j0*decim, min((j0+256)*decim, n)) for the sums: stage up to the end of it
+    long own_end = (j0 + 256) * decim;
+    if (own_end > n) own_end = n;
+    const long last = own_end - 1 > (j0 + jn - 1) * decim ? own_end - 1 : (j0 + jn - 1) * decim;
+    const int span = (int)(last - first + 1);
+    for (int i = threadIdx.x; i < ntaps; i += 256) c_s[i] = coef[i];
+    const int t = threadIdx.x;
+    // stage [first, first+span) into LDS with 16-byte loads, four in flight per lane, and take the integer
+    // I/Q sums (raw2iq.m:8) of the owned samples straight from the registers (v_sad_u8)
+    const long ao = (long)(((uintptr_t)base >> 1) & 7);
+    long mm = (first + ao) % 8;
+    if (mm < 0) mm += 8;
+    const long first_al = first - mm;                       // 16-byte aligned in memory
+    const int nchunk = (int)((first + span - first_al + 7) >> 3);
+    const long o0 = j0 * decim;
+    unsigned int si = 0, sq = 0;
+    for (int c0 = t; c0 < nchunk; c0 += 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 256 * u;
+            const long g0 = first_al + 8L * c;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchunk) {
+                if (g0 >= 0 && g0 + 8 <= n) {
+                    v[u] = *(const uint4*)(base + g0);
+                } else {
+                    unsigned short q[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = (g0 + i >= 0 && g0 + i < n) ? base[g0 + i] : (unsigned short)0;
+                    v[u].x = q[0] | ((unsigned)q[1] << 16); v[u].y = q[2] | ((unsigned)q[3] << 16);
+                    v[u].z = q[4] | ((unsigned)q[5] << 16); v[u].w = q[6] | ((unsigned)q[7] << 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 256 * u;
+            if (c >= nchunk) continue;
+            const long g0 = first_al + 8L * c;
+            *(uint4*)(r_s + lds_pad(8 * c)) = v[u];
+            if (g0 >= o0 && g0 + 8 <= own_end) {             // chunk fully owned (the common case)
+                const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                // sample = I | Q<<8: bytes 0,2 are I, bytes 1,3 are Q
+                    si = __builtin_amdgcn_sad_u8(w4[i] & 0x00FF00FFu, 0u, si);
+                    sq = __builtin_amdgcn_sad_u8(w4[i] & 0xFF00FF00u, 0u, sq);
+                }
+            } else if (g0 + 8 > o0 && g0 < own_end) {        // ragged edge: sample by sample
+                const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long g = g0 + i;
+                    if (g >= o0 && g < own_end) {
+                        const unsigned smp = (w4[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+                        si += smp & 0xFF;
+                        sq += smp >> 8;
+                    }
+                }
+            }
+        }
+    }
+    {
+        unsigned long long ti = si, tq = sq;
+        for (int off = 32; off > 0; off >>= 1) {
+            ti += __shfl_down(ti, off, 64);
+            tq += __shfl_down(tq, off, 64);
+        }
+        if ((t & 63) == 0) {
+            atomicAdd(&st[s].sum_i, ti);
+            atomicAdd(&st[s].sum_q, tq);
+        }
+    }
+    __syncthreads();
+    // (2) FIR of the raw samples, oldest tap first
+    if (t >= jn) return;
+    const long i_out = (j0 + t) * decim;
+    double ar = 0.0, ai = 0.0;
+    for (int k = ntaps - 1; k >= 0; --k) {
+        const long g = i_out - k;
+        if (g < 0) continue;                                 // zero initial state
+        const unsigned short v = r_s[lds_pad((int)(g - first_al))];
+        const double c = c_s[k];
+        ar = fma(c, (double)(v & 0xFF), ar);
+        ai = fma(c, (double)(v >> 8), ai);
+    }
+    out[(size_t)s * out_stride + j0 + t] = make_double2(ar, ai);
+}
+
+// ------------------------------------------------------------------------------------------------
 // filter(coef,1,s) on a complex array, keeping rows 1:decim:end.  grid (ceil(nd/256), D).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fir_arr(const cplx* __restrict__ in, long in_stride, long n,
