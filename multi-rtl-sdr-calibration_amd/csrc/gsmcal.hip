@@ -42,7 +42,7 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0;
+    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask;
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
 };
@@ -68,6 +68,7 @@ struct gsmcal_ctx {
     } g_calib, g_scan;
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
+    bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
     bool capturing = false;
     // shared workspace
     DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;
@@ -293,10 +294,35 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H);
-    LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
-           (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
-           peaks, H, g.NB);
-    LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
+    StepArgs sa_fine = sa;
+    if (c->prescreen) {
+        // two-pass fine search: packed-fp32 prescreen of every (bin, shift), exact fp64 on the candidates only
+        RET_IF(ensure(c, c->cur->p32, (size_t)S * H * g.nfft * sizeof(float)));
+        RET_IF(ensure(c, c->cur->cmask, (size_t)S * H * g.nfft * sizeof(unsigned short)));
+        RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
+        RET_IF(ensure(c, c->cur->esum, (size_t)S * H * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->cur->pmax32.p, 0, (size_t)S * H * sizeof(unsigned int), c->cur->stream));
+        const int nbp = (g.nfft / 2 + 255) / 256;          // two bins per lane
+        const int nstep_pad = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
+        LAUNCH(c, k_fine_prescreen, dim3(nbp, H, S), dim3(256), (size_t)nstep_pad * sizeof(float2),
+               (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
+               (float*)c->cur->p32.p, (unsigned short*)c->cur->cmask.p, (unsigned int*)c->cur->pmax32.p,
+               (double*)c->cur->esum.p, H);
+        if ((g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK > 2 * PS_NCHUNK) return GSMCAL_E_UNSUPPORTED;
+        const size_t tw_off = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) +
+                               (size_t)g.nfft * sizeof(unsigned short) + 15) & ~(size_t)15;
+        const size_t vlds = tw_off + (size_t)g.nfft * sizeof(cplx);
+        LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+               g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const float*)c->cur->p32.p,
+               (const unsigned short*)c->cur->cmask.p, (const unsigned int*)c->cur->pmax32.p,
+               (const double*)c->cur->esum.p, peaks, H, (int)tw_off);
+        sa_fine.NB = 1;
+    } else {
+        LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
+               (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
+               peaks, H, g.NB);
+    }
+    LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa_fine, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
     // and SNR gate fused per burst
     {
@@ -604,6 +630,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     // kernels whose dynamic LDS may exceed the 64 KiB default
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fine_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -619,6 +646,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     c->cur = &c->lanes[0];
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
+    const char* pe = getenv("GSMCAL_PRESCREEN");
+    if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
     *out = c;
@@ -650,7 +679,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);

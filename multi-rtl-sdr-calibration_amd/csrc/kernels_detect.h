@@ -520,16 +520,263 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 // Fine search, FCCH_fine_correction.m:48-52: argmax over the nshift = 128*ov+1 window starts of
 // max_k |FFT_nfft(window)|^2, as an exact sliding DFT in fp64: one bin per lane,
 //   X_k(m+1) = (X_k(m) + x[m+nfft] - x[m]) * exp(+2*pi*i*k/nfft),   X_k(0) from k_fft_burst<1>.
-// The hot loop is VALU-issue bound (every instruction costs ~4 cycles per wave), so it carries
-// only the recurrence (6 fp64 ops), |X|^2 (2) and ONE v_max_f64: steps are processed in chunks of
-// FS_CHUNK; per chunk the lane keeps the chunk maximum, and only when a chunk beats the running best
-// (strictly) does it remember the chunk index and the state the chunk started from.  After the loop
-// the block reduces to its winning lane ("larger power, then smaller start" = MATLAB's first-max rule
-// for max(max(|fft|^2,[],1))), and that lane alone replays its winning chunk -- the same operations
-// on the same operands, hence bit-identical powers -- to find the first step that attains the maximum.
+//
+// Two passes over the (bin, shift) plane:
+//  1. k_fine_prescreen (fp32): the same recurrence in single precision for EVERY bin, keeping only each
+//     bin's maximum power over the shifts and the window's overall maximum.  fp32 issues at twice the
+//     fp64 rate, and this pass has no argmax bookkeeping.
+//  2. k_fine_search (fp64): the exact recurrence, but only for CANDIDATE bins -- those whose fp32
+//     maximum amplitude lies within 2E of the window's fp32 maximum, where E bounds the fp32 error:
+//        |X32 - X| <= 1024 steps * ~5 ulp32 * (sum|x0 terms| + sum|d|) < 2^-10 * (sum|x[0..nfft)| + sum|d|)
+//     (triangle inequality on the unrolled recurrence; |re|+|im| is used as an upper bound of |z|).
+//     The bin holding the true fp64 maximum always passes this test, every passing bin is evaluated
+//     with the unchanged fp64 arithmetic, so the result equals that of running fp64 on all bins.
+//     Typically 1-3 of the 1184 bins are candidates.
+// The fp64 hot loop carries only the recurrence (6 ops), |X|^2 (2) and ONE v_max_f64: steps are
+// processed in chunks of FS_CHUNK; per chunk the lane keeps the chunk maximum, and only when a chunk
+// beats the running best (strictly) does it remember the chunk index and the state the chunk started
+// from.  After the loop the block reduces to its winning lane ("larger power, then smaller start" =
+// MATLAB's first-max rule for max(max(|fft|^2,[],1))), and that lane alone replays its winning chunk
+// -- the same operations on the same operands, hence bit-identical powers -- to find the first step
+// that attains the maximum.
 // grid (NB, H, S), block 256; bin k = blockIdx.x*256 + tid.  LDS: nshift-1 differences.
 // ------------------------------------------------------------------------------------------------
 #define FS_CHUNK 64
+#define FS_ERR_SCALE 0.0009765625   /* 2^-10 */
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// grid (NBP, H, S), block 256; lane g handles bins 2g and 2g+1 (packed fp32: v_pk_add/mul/fma_f32).
+// Outputs per bin: the fp32 maximum power over all shifts (p32) and a 16-bit mask of the FS_CHUNK-step
+// chunks whose fp32 maximum amplitude is within 2E of the bin's own maximum (chunk c covers shifts
+// 64c+1 .. 64c+64; bit 15 also stands for every later chunk when nshift > 1025).  Per window: the
+// overall fp32 maximum (pmax32, atomicMax on the float bits) and the error-bound sum esum.
+#define PS_NCHUNK 16
+__global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __restrict__ sts,
+                                                        const cplx* __restrict__ win, long win_stream_stride,
+                                                        long win_stride, int nshift, int nfft,
+                                                        const cplx* __restrict__ x0, float* __restrict__ p32,
+                                                        unsigned short* __restrict__ cmask,
+                                                        unsigned int* __restrict__ pmax32,
+                                                        double* __restrict__ esum, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* d = (float2*)smem;                  // nstep_pad differences, single precision (zero padded)
+    __shared__ double sh_e[4];
+    const int s = blockIdx.z, w = blockIdx.y;
+    if (w >= sts[s].n_win) return;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    const int tid = threadIdx.x;
+    const int nstep = nshift - 1;
+    const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
+    double e = 0.0;
+    for (int t = tid; t < nstep_pad; t += 256) {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (t < nstep) {
+            const cplx a = x[t + nfft], b = x[t];
+            const double dr = a.x - b.x, di = a.y - b.y;
+            v = make_float2((float)dr, (float)di);
+            e += fabs(dr) + fabs(di);
+        }
+        d[t] = v;
+    }
+    for (int t = tid; t < nfft; t += 256) e += fabs(x[t].x) + fabs(x[t].y);
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+    if ((tid & 63) == 0) sh_e[tid >> 6] = e;
+    __syncthreads();
+    const double es = sh_e[0] + sh_e[1] + sh_e[2] + sh_e[3];     // same value in every block of the window
+    if (blockIdx.x == 0 && tid == 0) esum[(size_t)s * H + w] = es;
+    const float twoE = (float)(2.0 * FS_ERR_SCALE * es * 1.0000002);   // rounded up
+    const int k0 = 2 * (blockIdx.x * 256 + tid);
+    float m = 0.0f;
+    if (k0 < nfft) {
+        const int k1 = k0 + 1 < nfft ? k0 + 1 : k0;
+        double wi0, wr0, wi1, wr1;
+        sincospi(2.0 * (double)k0 / (double)nfft, &wi0, &wr0);
+        sincospi(2.0 * (double)k1 / (double)nfft, &wi1, &wr1);
+        const v2f wr = {(float)wr0, (float)wr1}, wi = {(float)wi0, (float)wi1};
+        const cplx* x0w = x0 + ((size_t)s * H + w) * nfft;
+        v2f xr = {(float)x0w[k0].x, (float)x0w[k1].x}, xi = {(float)x0w[k0].y, (float)x0w[k1].y};
+        const v2f p0 = xr * xr + xi * xi;       // window start m = 0 (belongs to chunk 0 for the mask)
+        v2f cm[PS_NCHUNK];
+#pragma unroll
+        for (int c = 0; c < PS_NCHUNK; ++c) cm[c] = (v2f){0.0f, 0.0f};
+        cm[0] = p0;
+        const int nchunk = nstep_pad / FS_CHUNK;
+#pragma unroll
+        for (int c = 0; c < PS_NCHUNK; ++c) {
+            const int cend = (c == PS_NCHUNK - 1) ? nchunk : (c + 1 < nchunk ? c + 1 : nchunk);
+            for (int cc = c; cc < cend; ++cc) {          // one chunk per mask bit (the last bit takes any excess)
+                const float2* dc = d + cc * FS_CHUNK;
+                v2f best = cm[c];
+#pragma unroll 8
+                for (int t = 0; t < FS_CHUNK; ++t) {     // zero-padded steps only rotate X: |X| unchanged
+                    const float2 dv = dc[t];
+                    const v2f dr = {dv.x, dv.x}, di = {dv.y, dv.y};
+                    const v2f ar = xr + dr, ai = xi + di;
+                    xr = ar * wr - ai * wi;
+                    xi = ar * wi + ai * wr;
+                    const v2f p = xr * xr + xi * xi;
+                    best.x = fmaxf(best.x, p.x);
+                    best.y = fmaxf(best.y, p.y);
+                }
+                cm[c] = best;
+            }
+        }
+        v2f bm = cm[0];
+#pragma unroll
+        for (int c = 1; c < PS_NCHUNK; ++c) { bm.x = fmaxf(bm.x, cm[c].x); bm.y = fmaxf(bm.y, cm[c].y); }
+        const float t0 = sqrtf(bm.x) - twoE, t1 = sqrtf(bm.y) - twoE;
+        unsigned mk0 = 0, mk1 = 0;
+#pragma unroll
+        for (int c = 0; c < PS_NCHUNK; ++c) {
+            if (sqrtf(cm[c].x) * 1.0000002f >= t0) mk0 |= 1u << c;
+            if (sqrtf(cm[c].y) * 1.0000002f >= t1) mk1 |= 1u << c;
+        }
+        const size_t o = ((size_t)s * H + w) * nfft;
+        p32[o + k0] = bm.x;
+        cmask[o + k0] = (unsigned short)mk0;
+        if (k0 + 1 < nfft) { p32[o + k0 + 1] = bm.y; cmask[o + k0 + 1] = (unsigned short)mk1; }
+        m = fmaxf(bm.x, k0 + 1 < nfft ? bm.y : 0.0f);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    if ((tid & 63) == 0) atomicMax(&pmax32[(size_t)s * H + w], __float_as_uint(m));   // m >= 0: uint order == float order
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fine_verify: the exact (fp64) half of the fine search.  grid (H, S), block 256.
+// Work items = (candidate bin k, chunk c) pairs from the prescreen.  For each item the spectrum value
+// at the chunk's first shift is anchored by a direct fp64 DFT (all 64 lanes of a wave, fixed summation
+// order, table twiddles), then one lane slides through the chunk's 64 shifts with the fp64 recurrence
+// tracking (max power, first shift).  The block reduces with MATLAB's first-max rule (larger power, then
+// smaller shift, then smaller bin) into one PeakOut per window.
+// LDS: the 2208-sample window | item anchors | item list | per-bin chunk masks.
+// ------------------------------------------------------------------------------------------------
+#define FV_BINS 16                               /* bins per batch */
+#define FV_MAX_ITEMS (FV_BINS * PS_NCHUNK * 2)     /* >= FV_BINS * nchunk for ov <= 16 */
+__global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
+                                                     const cplx* __restrict__ win, long win_stream_stride,
+                                                     long win_stride, int nshift, int nfft,
+                                                     const cplx* __restrict__ tw_g, const float* __restrict__ p32,
+                                                     const unsigned short* __restrict__ cmask,
+                                                     const unsigned int* __restrict__ pmax32,
+                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H,
+                                                     int tw_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wlen = nshift - 1 + nfft;
+    cplx* xs = (cplx*)smem;                               // window
+    cplx* anchor = xs + wlen;                             // X_k at the chunk's first shift, per item
+    int* items = (int*)(anchor + FV_MAX_ITEMS);           // (k << 8) | chunk
+    unsigned short* cm_s = (unsigned short*)(items + FV_MAX_ITEMS);   // list of candidate bins
+    cplx* tw = (cplx*)(smem + tw_off);                     // nfft twiddles exp(-2 pi i m/nfft)
+    __shared__ int n_items, n_cand;
+    __shared__ double red_p[4];
+    __shared__ int red_t[4], red_k[4];
+    const int s = blockIdx.y, w = blockIdx.x;
+    if (w >= sts[s].n_win) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    if (tid == 0) n_items = 0;
+    for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
+    for (int i = tid; i < nfft; i += 256) tw[i] = tw_g[i];
+    __syncthreads();
+    const size_t o = ((size_t)s * H + w) * nfft;
+    const double E = FS_ERR_SCALE * esum[(size_t)s * H + w];
+    const double amax = sqrt((double)__uint_as_float(pmax32[(size_t)s * H + w]));
+    const int nstep = nshift - 1;
+    const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
+    // compact list of the candidate bins (amplitude within 2E of the window's fp32 maximum); cm_s[i] = bin
+    if (tid == 0) n_cand = 0;
+    __syncthreads();
+    for (int k = tid; k < nfft; k += 256)
+        if (sqrt((double)p32[o + k]) >= amax - 2.0 * E) cm_s[atomicAdd(&n_cand, 1)] = (unsigned short)k;
+    __syncthreads();
+    const int ncand = n_cand;
+    double best = -1.0;
+    int bt = 0x7fffffff, bk = 0x7fffffff;
+    // candidate bins are processed FV_BINS at a time, so the item list can never overflow whatever the input
+    // (an all-zero window makes every bin and chunk a candidate); normally there are 1-3 candidates: one pass
+    for (int kb = 0; kb < ncand; kb += FV_BINS) {
+        __syncthreads();
+        if (tid == 0) n_items = 0;
+        __syncthreads();
+        if (tid < FV_BINS && kb + tid < ncand) {
+            const int k = cm_s[kb + tid];
+            const unsigned mk = cmask[o + k];
+            for (int c = 0; c < nchunk; ++c) {
+                const int bit = c < PS_NCHUNK - 1 ? c : PS_NCHUNK - 1;
+                if (mk & (1u << bit)) {
+                    const int idx = atomicAdd(&n_items, 1);
+                    if (idx < FV_MAX_ITEMS) items[idx] = (k << 8) | c;
+                }
+            }
+        }
+        __syncthreads();
+        const int ni = n_items < FV_MAX_ITEMS ? n_items : FV_MAX_ITEMS;   // nchunk <= 2*PS_NCHUNK is checked on the host
+        if (ni == 0) continue;                               // block-uniform
+        // ---- anchors: wave-parallel direct DFT, item i handled by wave i % 4 ----
+        for (int i = wave; i < ni; i += 4) {
+            const int k = items[i] >> 8, c = items[i] & 0xFF;
+            const int t0 = c * FS_CHUNK;
+            double ar = 0.0, ai = 0.0;
+            int idx = (int)(((long)k * lane) % nfft);
+            const int stp = (int)(((long)k * 64) % nfft);
+#pragma unroll 4
+            for (int n = lane; n < nfft; n += 64) {
+                const cplx v = xs[t0 + n], t = tw[idx];
+                ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+                ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+                idx += stp;
+                if (idx >= nfft) idx -= nfft;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                ar += __shfl_down(ar, off, 64);
+                ai += __shfl_down(ai, off, 64);
+            }
+            if (lane == 0) anchor[i] = make_double2(ar, ai);
+        }
+        __syncthreads();
+        // ---- slides: one lane per item ----
+        for (int i = tid; i < ni; i += 256) {
+            const int k = items[i] >> 8, c = items[i] & 0xFF;
+            double wi, wr;
+            sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
+            double xr = anchor[i].x, xi = anchor[i].y;
+            const int t0 = c * FS_CHUNK;
+            if (c == 0) {                                    // the start window m = 0 belongs to chunk 0
+                const double p = xr * xr + xi * xi;
+                if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
+            }
+            const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
+            for (int j = 0; j < lim; ++j) {
+                const cplx a = xs[t0 + j + nfft], b = xs[t0 + j];
+                const double ar = xr + (a.x - b.x), ai = xi + (a.y - b.y);
+                xr = ar * wr - ai * wi;
+                xi = ar * wi + ai * wr;
+                const double p = xr * xr + xi * xi;
+                const int m = t0 + j + 1;
+                if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double op = __shfl_down(best, off, 64);
+        const int ot = __shfl_down(bt, off, 64);
+        const int ok = __shfl_down(bk, off, 64);
+        if (op > best || (op == best && (ot < bt || (ot == bt && ok < bk)))) { best = op; bt = ot; bk = ok; }
+    }
+    if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; ++i)
+            if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
+                best = red_p[i]; bt = red_t[i]; bk = red_k[i];
+            }
+        PeakOut o2; o2.p = best; o2.tie = bt; o2.k = bk;
+        out[(size_t)s * H + w] = o2;
+    }
+}
+
+// The all-bins fp64 search (GSMCAL_PRESCREEN=0): kept as the ablation / cross-check of the two-pass scheme.
 __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restrict__ sts,
                                                      const cplx* __restrict__ win, long win_stream_stride,
                                                      long win_stride, int nshift, int nfft,
@@ -545,6 +792,8 @@ __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restri
     const int tid = threadIdx.x;
     const int nstep = nshift - 1;
     const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
+    const int k = blockIdx.x * 256 + tid;
+    const bool cand = k < nfft;
     for (int t = tid; t < nstep_pad; t += 256) {
         cplx v = make_double2(0.0, 0.0);
         if (t < nstep) {
@@ -554,12 +803,11 @@ __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restri
         d[t] = v;
     }
     __syncthreads();
-    const int k = blockIdx.x * 256 + tid;
     double best = -1.0;          // running best power of this bin
     int best_c = -1;             // chunk that attained it (-1: the start window m = 0)
     double sxr = 0.0, sxi = 0.0; // state at the start of that chunk
     double wr = 1.0, wi = 0.0;
-    if (k < nfft) {
+    if (cand) {
         sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
         const cplx xi0 = x0[((size_t)s * H + w) * nfft + k];
         double xr = xi0.x, xi = xi0.y;
@@ -593,7 +841,7 @@ __global__ void __launch_bounds__(256) k_fine_search(const StreamState* __restri
     }
     // block winner: larger power, then earlier chunk, then smaller bin
     double rb = best;
-    int rc = k < nfft ? best_c : 0x7ffffff0, rk = k;
+    int rc = cand ? best_c : 0x7ffffff0, rk = k;
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(rb, off, 64);
         const int oc = __shfl_down(rc, off, 64);
