@@ -212,13 +212,7 @@ struct Source {
 };
 
 size_t gather_lds(int len, int level, int kind, int ntaps, bool to_lds = false) {
-    // must mirror the carve at the top of gather_core
-    const size_t bufn = (level >= 1 || to_lds) ? (size_t)len + 8 : 0;
-    size_t b = bufn * sizeof(cplx) * ((level >= 2 || to_lds) ? 2 : 1) + (size_t)((ntaps + 1) & ~1) * 8;
-    const size_t span_max = (size_t)len + 8 + ntaps + 24;
-    b += ((span_max + 7) & ~(size_t)7) * 2;
-    if (kind == SRC_RAW) b += (span_max + span_max / 4 + 16) * sizeof(cplx);
-    return (b + 15) & ~(size_t)15;
+    return gather_carve(len, level, kind, ntaps, to_lds).total;
 }
 
 GatherArgs gather_args(const Source& src, int level, int len) {
@@ -230,11 +224,9 @@ GatherArgs gather_args(const Source& src, int level, int len) {
     return a;
 }
 
-// LDS of a fused gather + estimator kernel: the gather carve, or the two window buffers plus `scratch`
+// LDS of a fused gather + estimator kernel: the gather carve followed by `scratch` bytes
 size_t fused_lds(const Source& src, int level, int len, size_t scratch) {
-    const size_t g = gather_lds(len, level, src.kind, src.ntaps, true);
-    const size_t alt = (size_t)2 * (len + 8) * sizeof(cplx) + scratch;
-    return ((g > alt ? g : alt) + 15) & ~(size_t)15;
+    return (gather_carve(len, level, src.kind, src.ntaps, true).total + scratch + 15) & ~(size_t)15;
 }
 
 int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, bool tiles, int nwin_grid,
@@ -259,8 +251,8 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
     return 0;
 }
 
-size_t burst_scratch(const Geom& g) {   // B[37][N2+1] | w37 (40) | wN2 | P[2*hnl <= 2*nfft/16]
-    return ((size_t)37 * (g.nfft / 37 + 1) + 40 + g.nfft / 37) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
+size_t burst_scratch(const Geom& g) {   // w37 (40) | wN2 | P[2*hnl <= nfft/4]   (B lives in the free gather buffer)
+    return ((size_t)40 + g.nfft / 37) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
 }
 
 size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
@@ -286,6 +278,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
     RET_IF(ensure(c, c->cur->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
     RET_IF(ensure(c, c->cur->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
+    RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
     RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->cur->win.p;
     PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
@@ -293,7 +286,8 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
-           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H);
+           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H,
+           c->prescreen ? (unsigned int*)c->cur->pmax32.p : (unsigned int*)nullptr);
     StepArgs sa_fine = sa;
     if (c->prescreen) {
         // two-pass fine search: packed-fp32 prescreen of every (bin, shift), exact fp64 on the candidates only
@@ -301,7 +295,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         RET_IF(ensure(c, c->cur->cmask, (size_t)S * H * g.nfft * sizeof(unsigned short)));
         RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
         RET_IF(ensure(c, c->cur->esum, (size_t)S * H * sizeof(double)));
-        HIPCHK(c, hipMemsetAsync(c->cur->pmax32.p, 0, (size_t)S * H * sizeof(unsigned int), c->cur->stream));
         const int nbp = (g.nfft / 2 + 255) / 256;          // two bins per lane
         const int nstep_pad = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
         LAUNCH(c, k_fine_prescreen, dim3(nbp, H, S), dim3(256), (size_t)nstep_pad * sizeof(float2),
@@ -309,13 +302,12 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                (float*)c->cur->p32.p, (unsigned short*)c->cur->cmask.p, (unsigned int*)c->cur->pmax32.p,
                (double*)c->cur->esum.p, H);
         if ((g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK > 2 * PS_NCHUNK) return GSMCAL_E_UNSUPPORTED;
-        const size_t tw_off = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) +
-                               (size_t)g.nfft * sizeof(unsigned short) + 15) & ~(size_t)15;
-        const size_t vlds = tw_off + (size_t)g.nfft * sizeof(cplx);
+        const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) +
+                             (size_t)g.nfft * sizeof(unsigned short) + 15) & ~(size_t)15;
         LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
                g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const float*)c->cur->p32.p,
                (const unsigned short*)c->cur->cmask.p, (const unsigned int*)c->cur->pmax32.p,
-               (const double*)c->cur->esum.p, peaks, H, (int)tw_off);
+               (const double*)c->cur->esum.p, peaks, H);
         sa_fine.NB = 1;
     } else {
         LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),

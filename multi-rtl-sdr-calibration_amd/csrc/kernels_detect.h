@@ -466,7 +466,8 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
                                                            const cplx* __restrict__ win, long win_stream_stride,
                                                            long win_stride, int nfft,
                                                            const cplx* __restrict__ tw_g, PeakOut* __restrict__ peaks,
-                                                           cplx* __restrict__ x0, int H) {
+                                                           cplx* __restrict__ x0, int H,
+                                                           unsigned int* __restrict__ pmax32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N2 = nfft / 37;
     const int ldb = N2 + 1;                     // padded row: conflict-free column reads in step 2
@@ -479,6 +480,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x;
+    if (MODE == 1 && pmax32 && tid == 0) pmax32[(size_t)s * H + w] = 0u;   // reset for k_fine_prescreen's atomicMax
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < nfft; i += FFT_THREADS) xs[i] = x[i];
     fft37_tables(w37, wN2, N2, tid);
@@ -659,15 +661,13 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
                                                      const cplx* __restrict__ tw_g, const float* __restrict__ p32,
                                                      const unsigned short* __restrict__ cmask,
                                                      const unsigned int* __restrict__ pmax32,
-                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H,
-                                                     int tw_off) {
+                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wlen = nshift - 1 + nfft;
     cplx* xs = (cplx*)smem;                               // window
     cplx* anchor = xs + wlen;                             // X_k at the chunk's first shift, per item
     int* items = (int*)(anchor + FV_MAX_ITEMS);           // (k << 8) | chunk
     unsigned short* cm_s = (unsigned short*)(items + FV_MAX_ITEMS);   // list of candidate bins
-    cplx* tw = (cplx*)(smem + tw_off);                     // nfft twiddles exp(-2 pi i m/nfft)
     __shared__ int n_items, n_cand;
     __shared__ double red_p[4];
     __shared__ int red_t[4], red_k[4];
@@ -677,7 +677,6 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     if (tid == 0) n_items = 0;
     for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
-    for (int i = tid; i < nfft; i += 256) tw[i] = tw_g[i];
     __syncthreads();
     const size_t o = ((size_t)s * H + w) * nfft;
     const double E = FS_ERR_SCALE * esum[(size_t)s * H + w];
@@ -722,7 +721,7 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
             const int stp = (int)(((long)k * 64) % nfft);
 #pragma unroll 4
             for (int n = lane; n < nfft; n += 64) {
-                const cplx v = xs[t0 + n], t = tw[idx];
+                const cplx v = xs[t0 + n], t = tw_g[idx];   // L2-resident table, 4 loads in flight
                 ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
                 ai = fma(v.x, t.y, fma(v.y, t.x, ai));
                 idx += stp;

@@ -28,8 +28,8 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 // 1184-point spectrum argmax in fftshift order, integer-bin derotation, unit-phasor phase step
 // (FCCH_fine_correction.m:148-155 / carrier_correct_post_SCH.m:63-72) and, for GATE, the SNR gate
 // (:185-189).  grid (H, S), block 512.  Writes st->fo_burst[w] and (GATE) st->snr_burst[w].
-// LDS: the gather carve (kernels_frontend.h); once the window is in buf0/buf1 the rest of the carve is
-// dead and is reused for B[37][N2+1] | w37 | wN2 | P[2*hnl].
+// LDS: the gather carve (kernels_frontend.h); the window ends up in buf0 or buf1, the other buffer then
+// holds B[37][N2+1]; w37 | wN2 | P[2*hnl] follow the carve.  ~48 KB: three workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define BT_THREADS 512
 template <int GATE>
@@ -47,8 +47,10 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
     __syncthreads();
     StreamState* st = sts + s;
     const int N2 = nfft / 37, ldb = N2 + 1;
-    cplx* B = (cplx*)(smem + (size_t)2 * (a.len + 8) * sizeof(cplx));
-    cplx* w37 = B + 37 * ldb;
+    // the window sits in one of the two gather buffers; the other one holds B, the tables go behind the carve
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true);
+    cplx* B = (xs == (cplx*)smem) ? (cplx*)(smem + gc.off_region1) : (cplx*)smem;
+    cplx* w37 = (cplx*)(smem + gc.total);
     cplx* wN2 = w37 + 40;
     double* P = (double*)(wN2 + N2);
     fft37_tables(w37, wN2, N2, tid);
@@ -163,7 +165,8 @@ __global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ st
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
     if (!xs) return;
-    cplx* tc = (cplx*)(smem + (size_t)2 * (a.len + 8) * sizeof(cplx));   // conj(ts)
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true);
+    cplx* tc = (cplx*)(smem + gc.total);                                  // conj(ts), behind the gather carve
     cplx* part = tc + len_ts;                                             // nshift * SCH_PARTS partial sums
     double* cv = (double*)(part + nshift * SCH_PARTS);                    // nshift correlation powers
     __syncthreads();

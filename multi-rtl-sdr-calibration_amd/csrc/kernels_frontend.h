@@ -339,22 +339,44 @@ __device__ __forceinline__ long level_len(const StreamState* st, int level) {
 // samples 4 apart (the 4-outputs-per-lane FIR below) hit distinct banks with ds_read_b128.
 __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 
+// LDS layout of gather_core (byte offsets from the dynamic LDS base); also used by the host to size launches.
+struct GatherCarve {
+    size_t bufn;          // elements per window buffer (0: none)
+    size_t off_region1;   // buf1 / xs
+    size_t off_coef, off_raw, total;
+};
+__host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind, int ntaps, bool to_lds) {
+    GatherCarve g;
+    g.bufn = (level >= 1 || to_lds) ? (size_t)len + 40 : 0;          // +40: room for B[37][N2+1] of the fused kernels
+    const size_t span_max = (size_t)len + 8 + ntaps + 24;
+    const size_t xs_n = kind == SRC_RAW ? span_max + span_max / 4 + 16 : 0;   // padded input (raw sources only)
+    const bool need_buf1 = level >= 2 || (to_lds && level >= 1) || to_lds;
+    size_t r1 = need_buf1 ? g.bufn : 0;
+    if (xs_n > r1) r1 = xs_n;
+    g.off_region1 = g.bufn * 16;
+    g.off_coef = g.off_region1 + r1 * 16;
+    g.off_raw = g.off_coef + (size_t)((ntaps + 1) & ~1) * 8;
+    g.total = (g.off_raw + ((span_max + 7) & ~(size_t)7) * 2 + 15) & ~(size_t)15;
+    return g;
+}
+
 // gather_core<NT>: the body shared by k_gather and the fused per-window kernels (kernels_estim.h).
 // to_lds = false: the window is written to global memory (a.dst).  to_lds = true: the last level
 // stays in LDS and its address is returned (nullptr if this block has no window).
 // The block's window index is `widx`, its stream `s`.  smem: the dynamic LDS base, carved as
-//   buf0 | buf1 | coef | raw ushorts | xs (padded complex input)          (host: gather_lds()).
+//   buf0 | buf1 (aliased with the padded complex input xs) | coef | raw ushorts     (GatherCarve).
 template <int NT>
 __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts, const GatherArgs& a,
                                              unsigned char* smem, int widx, int s, bool to_lds) {
-    // LDS carve (host: gather_lds): buf0 | buf1 | coef | raw ushorts | xs (padded complex input)
-    const int bufn = (a.level >= 1 || to_lds) ? a.len + 8 : 0;     // to_lds: always two buffers
+    // LDS carve (GatherCarve, shared with the host and the fused kernels):
+    //   buf0 | region1 = buf1 ALIASED WITH xs (padded complex input) | coef | raw ushorts
+    // xs is dead once level 0 is in buf0, and buf1 is first written at level 1, so they share storage.
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, to_lds);
     cplx* buf0 = (cplx*)smem;
-    cplx* buf1 = buf0 + bufn;
-    double* c_s = (double*)(buf1 + ((a.level >= 2 || to_lds) ? bufn : 0));
-    unsigned short* r_s = (unsigned short*)(c_s + ((a.ntaps + 1) & ~1));
-    const int span_max = a.len + 8 + a.ntaps + 24;
-    cplx* xs = (cplx*)(r_s + ((span_max + 7) & ~7));
+    cplx* buf1 = (cplx*)(smem + gc.off_region1);
+    cplx* xs = buf1;
+    double* c_s = (double*)(smem + gc.off_coef);
+    unsigned short* r_s = (unsigned short*)(smem + gc.off_raw);
     const StreamState* st = sts + s;
     const int level = a.level;
     long start, L;
