@@ -252,7 +252,7 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
 }
 
 size_t burst_scratch(const Geom& g) {   // w37 (40) | wN2 | P[2*hnl <= nfft/4]   (B lives in the free gather buffer)
-    return ((size_t)40 + g.nfft / 37) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
+    return ((size_t)40 + g.nfft / 37 + 16 + g.nfft / 16 + 2) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
 }
 
 size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
@@ -320,7 +320,35 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     {
         const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
         LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov);
+               g.nfft, (const cplx*)c->tw.p, g.ov, 1);
+    }
+    if (getenv("GSMCAL_DBG_BT")) {
+        const size_t nb = (size_t)S * H;
+        RET_IF(ensure(c, c->misc, nb * 16 * 8));
+        (void)hipStreamSynchronize(c->cur->stream);
+        (void)hipMemset(c->misc.p, 0, nb * 16 * 8);
+        void* p = c->misc.p;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_dbg), &p, sizeof(p));
+        const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
+        LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
+               g.nfft, (const cplx*)c->tw.p, g.ov, 1);
+        (void)hipStreamSynchronize(c->cur->stream);
+        std::vector<unsigned long long> h(nb * 16);
+        (void)hipMemcpy(h.data(), p, h.size() * 8, hipMemcpyDeviceToHost);
+        void* z = nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_dbg), &z, sizeof(z));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double ph[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        for (size_t b = 0; b < nb; ++b) {
+            if (!h[b * 16 + 4]) continue;
+            if (h[b * 16] < t0) t0 = h[b * 16];
+            if (h[b * 16 + 4] > t1) t1 = h[b * 16 + 4];
+            for (int i = 0; i < 4; ++i) ph[i] += (h[b * 16 + i + 1] - h[b * 16 + i]) / 100.0;
+            ++cnt;
+        }
+        fprintf(stderr, "burst_tone<1>: %d blocks, span %.1f us; mean phase us: gather %.1f fft+argmax %.1f tone %.1f gate %.1f\n",
+                cnt, (t1 - t0) / 100.0, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
     }
     if (next_sch_lvl >= 0)
         LAUNCH(c, k_step<STEP_CARRIER_DECIDE | STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_sch_lvl);
@@ -371,7 +399,7 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     {
         const GatherArgs ga = gather_args(src, lvl, g.nfft);
         LAUNCH(c, k_burst_tone<0>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov);
+               g.nfft, (const cplx*)c->tw.p, g.ov, 0);
     }
     if (table)
         LAUNCH(c, k_step<STEP_POST_DECIDE | STEP_TOTALS>, dim3(S), dim3(64), 0, st, sa, lvl, 0);

@@ -32,9 +32,11 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 // holds B[37][N2+1]; w37 | wN2 | P[2*hnl] follow the carve.  ~48 KB: three workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define BT_THREADS 512
+__device__ unsigned long long* g_bt_dbg = nullptr;   // development aid: per-phase timestamps of k_burst_tone
+#define BT_STAMP(i) do { if (g_bt_dbg && tid == 0) g_bt_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 template <int GATE>
 __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft,
-                                                           const cplx* __restrict__ tw_g, int ov) {
+                                                           const cplx* __restrict__ tw_g, int ov, int prior_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red_p[BT_THREADS / 64];
     __shared__ int red_t[BT_THREADS / 64];
@@ -42,9 +44,11 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
     __shared__ double sh_phase;
     __shared__ int sh_key;
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    BT_STAMP(0);
     cplx* xs = gather_core<BT_THREADS>(sts, a, smem, w, s, true);   // nfft samples of the burst, in LDS
     if (!xs) return;                                                // block-uniform
     __syncthreads();
+    BT_STAMP(1);
     StreamState* st = sts + s;
     const int N2 = nfft / 37, ldb = N2 + 1;
     // the window sits in one of the two gather buffers; the other one holds B, the tables go behind the carve
@@ -56,55 +60,112 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
     fft37_tables(w37, wN2, N2, tid);
     __syncthreads();
     // ---- spectrum argmax, first max in fftshift order (:149-150) ----
-    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
-    __syncthreads();
-    double best = -1.0;
-    int key = 0x7fffffff;
-    for (int k = tid; k < nfft; k += BT_THREADS) {
-        const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
-        const double p = X.x * X.x + X.y * X.y;
-        const int sk = (k + nfft / 2) % nfft;
-        if (p > best || (p == best && sk < key)) { best = p; key = sk; }
+    // Fast exact route: the window is centred on the FCCH tone, so nearly all of its energy sits in a few bins
+    // around a known prior (the fine search's winning bin; bin 37 = symbol_rate/4 once the carrier is
+    // corrected).  Evaluate the 7 bins prior-3..prior+3 directly (one wave each) and use Parseval,
+    //   sum_k |X_k|^2 = N * sum_n |x[n]|^2,
+    // to bound every other bin by R = N*E - sum(candidates); if R < max(candidates) the global first-max is
+    // among the candidates.  Otherwise (weak or absent tone) fall back to the full 37 x N2 spectrum.
+    {
+        double e = 0.0;
+        for (int n = tid; n < nfft; n += BT_THREADS) { const cplx v = xs[n]; e = fma(v.x, v.x, fma(v.y, v.y, e)); }
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = e;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int prior = prior_mode == 1 ? st->prior_bin[w] : nfft / 32;       // 37 for every oversampling ratio
+        if (wave < 7) {
+            int k = prior - 3 + wave;
+            k = ((k % nfft) + nfft) % nfft;
+            double ar = 0.0, ai = 0.0;
+            int idx = (int)(((long)k * lane) % nfft);
+            const int stp = (int)(((long)k * 64) % nfft);
+#pragma unroll 4
+            for (int n = lane; n < nfft; n += 64) {
+                const cplx v = xs[n], t = tw_g[idx];
+                ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+                ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+                idx += stp;
+                if (idx >= nfft) idx -= nfft;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                ar += __shfl_down(ar, off, 64);
+                ai += __shfl_down(ai, off, 64);
+            }
+            if (lane == 0) { red_p[wave] = ar * ar + ai * ai; red_t[wave] = (k + nfft / 2) % nfft; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double etot = 0.0;
+            for (int i = 0; i < BT_THREADS / 64; ++i) etot += red[i];
+            double best = -1.0, sum = 0.0;
+            int key = 0x7fffffff;
+            for (int i = 0; i < 7; ++i) {
+                sum += red_p[i];
+                if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; }
+            }
+            const double R = (double)nfft * etot - sum;           // energy left for all the other bins together
+            sh_key = (best > 0.0 && R * 1.000001 + 1e-300 < best) ? key : -1;
+        }
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double op = __shfl_down(best, off, 64);
-        const int ok = __shfl_down(key, off, 64);
-        if (op > best || (op == best && ok < key)) { best = op; key = ok; }
+    if (sh_key < 0) {                                              // block-uniform: proof failed, full spectrum
+        fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
+        __syncthreads();
+        double best = -1.0;
+        int key = 0x7fffffff;
+        for (int k = tid; k < nfft; k += BT_THREADS) {
+            const cplx X = fft37_step2_bin(B, wN2, N2, ldb, k);
+            const double p = X.x * X.x + X.y * X.y;
+            const int sk = (k + nfft / 2) % nfft;
+            if (p > best || (p == best && sk < key)) { best = p; key = sk; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double op = __shfl_down(best, off, 64);
+            const int ok = __shfl_down(key, off, 64);
+            if (op > best || (op == best && ok < key)) { best = op; key = ok; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red_p[tid >> 6] = best; red_t[tid >> 6] = key; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < BT_THREADS / 64; ++i)
+                if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; }
+            sh_key = key;
+        }
+        __syncthreads();
     }
-    if ((tid & 63) == 0) { red_p[tid >> 6] = best; red_t[tid >> 6] = key; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 1; i < BT_THREADS / 64; ++i)
-            if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; }
-        sh_key = key;
-    }
-    __syncthreads();
+    BT_STAMP(2);
     const int max_idx = sh_key + 1;                                    // 1-based index after fftshift
     const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
     // :151  int_phase_rotate = 2.*pi.*(max_idx - ((fft_len/2)+1))./fft_len
     const double ipr = (TWO_PI_D * (double)(max_idx - (nfft / 2 + 1))) / (double)nfft;
-    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)   (in place)
-    for (int n = tid; n < nfft; n += BT_THREADS) {
-        double sn, cs;
-        sincos((double)n * ipr, &sn, &cs);
-        xs[n] = cmul(xs[n], make_double2(cs, -sn));
+    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)   (in place).  int_phase_rotate is an
+    // integer number of bins j, so exp(-1i*n*ipr) = exp(-2*pi*i*(n*j mod N)/N): taken from the exact table
+    // (the reference's fl(n*ipr) differs from it by < 1e-12 rad, far below what the estimator resolves).
+    {
+        const int jb = max_idx - (nfft / 2 + 1);
+        const int jm = jb < 0 ? jb + nfft : jb;
+        for (int n = tid; n < nfft; n += BT_THREADS) {
+            const cplx t = tw_g[(int)(((long)n * jm) % nfft)];
+            xs[n] = cmul(xs[n], t);
+        }
     }
     __syncthreads();
     // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) ): unit phasors u[n] = x/|x| once
-    // per sample (into the dead B region), then the complex quotients u[n+1]/u[n]
+    // per sample (into the dead B region), then u[n+1]*conj(u[n]) (the quotient of two unit phasors)
     cplx* u = B;
     for (int n = tid; n < nfft; n += BT_THREADS) {
         const cplx p0 = xs[n];
-        const double m = hypot(p0.x, p0.y);
-        u[n] = m > 0.0 ? make_double2(p0.x / m, p0.y / m) : make_double2(1.0, 0.0);   // angle(0) = 0
+        const double m2 = p0.x * p0.x + p0.y * p0.y;
+        const double inv = rsqrt(m2);
+        u[n] = m2 > 0.0 ? make_double2(p0.x * inv, p0.y * inv) : make_double2(1.0, 0.0);   // angle(0) = 0
     }
     __syncthreads();
     double sr = 0.0, si = 0.0;
     for (int n = tid; n < nfft - 1; n += BT_THREADS) {
         const cplx ua = u[n + 1], ub = u[n];
-        const double den = ub.x * ub.x + ub.y * ub.y;
-        sr += (ua.x * ub.x + ua.y * ub.y) / den;
-        si += (ua.y * ub.x - ua.x * ub.y) / den;
+        sr += ua.x * ub.x + ua.y * ub.y;
+        si += ua.y * ub.x - ua.x * ub.y;
     }
     for (int off = 32; off > 0; off >>= 1) {
         sr += __shfl_down(sr, off, 64);
@@ -120,15 +181,26 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
         sh_phase = phase;
         st->fo_burst[w] = sampling_rate * (ipr + phase) / TWO_PI_D;   // :155
     }
+    BT_STAMP(3);
     if (!GATE) return;
     __syncthreads();
     // ---- SNR gate, FCCH_fine_correction.m:185-189: bins [0,hnl) and [nfft-hnl,nfft) only ----
+    // exp(-1i*n*phase) = base[n/16] * pw[n%16]: accurate sincos only for the 16 powers and every 16th sample
+    // (the gate is a 5 dB threshold on band powers; 1e-16-level phase differences cannot move it)
     const double phase = sh_phase;
-    for (int n = tid; n < nfft; n += BT_THREADS) {
+    cplx* pw = (cplx*)P;                       // 16 entries; P proper is written after the barrier below
+    cplx* base = pw + 16;                      // nfft/16 + 1 entries
+    if (tid < 16) {
         double sn, cs;
-        sincos((double)n * phase, &sn, &cs);
-        xs[n] = cmul(xs[n], make_double2(cs, -sn));
+        sincos((double)tid * phase, &sn, &cs);
+        pw[tid] = make_double2(cs, -sn);
+    } else if (tid >= 64 && tid < 64 + (nfft + 15) / 16) {
+        double sn, cs;
+        sincos((double)((tid - 64) * 16) * phase, &sn, &cs);
+        base[tid - 64] = make_double2(cs, -sn);
     }
+    __syncthreads();
+    for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], cmul(base[n >> 4], pw[n & 15]));
     __syncthreads();
     fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
     __syncthreads();
@@ -150,6 +222,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restri
         for (int k = hnl; k < nb - 2; ++k) noi += P[k];
         st->snr_burst[w] = 10.0 * log10(sig / noi);
     }
+    BT_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -581,6 +654,7 @@ __global__ void __launch_bounds__(64) k_step(StreamState* __restrict__ sts, Step
         // merge the NB partial peaks of window `lane` (the loads of all windows are in flight together)
         const PeakOut pk = merge_peaks(a.peaks + ((size_t)s * a.H + lane) * a.NB, a.NB);
         sh.fine_first[lane] = (double)(sh.win_start[lane] + 1 + pk.tie);          // sp + max_idx - 1
+        sh.prior_bin[lane] = pk.k;
     }
     if (STEPS & STEP_FINE_DECIDE) __syncthreads();
     if (lane == 0) {

@@ -54,6 +54,7 @@ struct alignas(16) StreamState {
     double fcch_pos[MAXH];
     double sampling_ppm1, carrier_ppm1;
     double fo_burst[MAXH], snr_burst[MAXH];
+    int prior_bin[MAXH];     // fine search's winning bin per hit: where the burst spectrum's peak is expected
     int r1_kind;             // what FCCH_fine_correction returns as r: 0 = -1, 1 = s, 2 = lerp only, 3 = lerp+mix
     // ---- SCH ----
     int n_sch_first;
