@@ -42,7 +42,7 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask;
+    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert;
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
 };
@@ -69,6 +69,8 @@ struct gsmcal_ctx {
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
+    bool certify = false;           // GSMCAL_CERT=1: Parseval certificate before the prescreen (experiment: exact, but the
+                                    // certificate kernel currently costs more than the prescreen work it saves)
     bool capturing = false;
     // shared workspace
     DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;
@@ -295,19 +297,29 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         RET_IF(ensure(c, c->cur->cmask, (size_t)S * H * g.nfft * sizeof(unsigned short)));
         RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
         RET_IF(ensure(c, c->cur->esum, (size_t)S * H * sizeof(double)));
+        const FineCert* certp = nullptr;
+        if (c->certify) {
+            RET_IF(ensure(c, c->cur->cert, (size_t)S * H * sizeof(FineCert)));
+            const int nchunk = (g.fine_nshift - 1 + FC_CHUNK - 1) / FC_CHUNK;
+            const size_t clds = ((size_t)g.fine_wlen * sizeof(cplx) + (size_t)(g.fine_wlen + 2) * sizeof(double) +
+                                 (size_t)(g.fine_nshift + 2) * sizeof(double) + (size_t)FC_NB * nchunk * sizeof(cplx) + 15) & ~(size_t)15;
+            LAUNCH(c, k_fine_cert, dim3(H, S), dim3(256), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const cplx*)c->cur->x0.p, (FineCert*)c->cur->cert.p, H);
+            certp = (const FineCert*)c->cur->cert.p;
+        }
         const int nbp = (g.nfft / 2 + 255) / 256;          // two bins per lane
         const int nstep_pad = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
         LAUNCH(c, k_fine_prescreen, dim3(nbp, H, S), dim3(256), (size_t)nstep_pad * sizeof(float2),
                (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
                (float*)c->cur->p32.p, (unsigned short*)c->cur->cmask.p, (unsigned int*)c->cur->pmax32.p,
-               (double*)c->cur->esum.p, H);
+               (double*)c->cur->esum.p, H, certp);
         if ((g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK > 2 * PS_NCHUNK) return GSMCAL_E_UNSUPPORTED;
         const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) +
                              (size_t)g.nfft * sizeof(unsigned short) + 15) & ~(size_t)15;
         LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
                g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const float*)c->cur->p32.p,
                (const unsigned short*)c->cur->cmask.p, (const unsigned int*)c->cur->pmax32.p,
-               (const double*)c->cur->esum.p, peaks, H);
+               (const double*)c->cur->esum.p, peaks, H, certp);
         sa_fine.NB = 1;
     } else {
         LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
@@ -651,6 +663,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fine_cert, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -666,6 +679,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     c->cur = &c->lanes[0];
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
+    const char* ce = getenv("GSMCAL_CERT");
+    if (ce) c->certify = atoi(ce) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* ge = getenv("GSMCAL_GRAPH");
@@ -699,7 +714,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);

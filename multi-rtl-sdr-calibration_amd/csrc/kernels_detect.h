@@ -546,6 +546,45 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 #define FS_CHUNK 64
 #define FS_ERR_SCALE 0.0009765625   /* 2^-10 */
 
+// X_k at one shift by a direct fp64 DFT over the nfft samples xw[0..nfft), executed by one wave: lane l sums
+// the terms n = l, l+64, ... (fixed order), then a shuffle tree adds the 64 partials.  The 19 table loads of a
+// pass are independent and issued together (the twiddle table lives in L2).  Returns the value in lane 0.
+__device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __restrict__ tw_g, int nfft, int lane) {
+    double ar = 0.0, ai = 0.0;
+    const int stp = (int)(((long)k * 64) % nfft);
+    int idx = (int)(((long)k * lane) % nfft);
+    for (int n0 = 0; n0 < nfft; n0 += 19 * 64) {
+        cplx t[19];
+        int id = idx;
+#pragma unroll
+        for (int u = 0; u < 19; ++u) {
+            t[u] = tw_g[id];
+            id += stp;
+            if (id >= nfft) id -= nfft;
+        }
+        idx = id;
+#pragma unroll
+        for (int u = 0; u < 19; ++u) {
+            const int n = n0 + lane + 64 * u;
+            if (n < nfft) {
+                const cplx v = xw[n];
+                ar = fma(v.x, t[u].x, fma(-v.y, t[u].y, ar));
+                ai = fma(v.x, t[u].y, fma(v.y, t[u].x, ai));
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ar += __shfl_down(ar, off, 64);
+        ai += __shfl_down(ai, off, 64);
+    }
+    return make_double2(ar, ai);
+}
+
+// result of k_fine_cert for one window (see below)
+struct FineCert { double p; int t, k, a, b; int pad; };
+#define FC_NB 7
+#define FC_CHUNK 256   /* shifts per anchored segment in k_fine_cert */
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // grid (NBP, H, S), block 256; lane g handles bins 2g and 2g+1 (packed fp32: v_pk_add/mul/fma_f32).
@@ -560,12 +599,17 @@ __global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __res
                                                         const cplx* __restrict__ x0, float* __restrict__ p32,
                                                         unsigned short* __restrict__ cmask,
                                                         unsigned int* __restrict__ pmax32,
-                                                        double* __restrict__ esum, int H) {
+                                                        double* __restrict__ esum, int H,
+                                                        const FineCert* __restrict__ cert) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* d = (float2*)smem;                  // nstep_pad differences, single precision (zero padded)
     __shared__ double sh_e[4];
     const int s = blockIdx.z, w = blockIdx.y;
     if (w >= sts[s].n_win) return;
+    if (cert) {                                 // fully certified window: nothing left to search
+        const FineCert fc = cert[(size_t)s * H + w];
+        if (fc.a == 0 && fc.b == nshift - 1) return;
+    }
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     const int tid = threadIdx.x;
     const int nstep = nshift - 1;
@@ -661,7 +705,8 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
                                                      const cplx* __restrict__ tw_g, const float* __restrict__ p32,
                                                      const unsigned short* __restrict__ cmask,
                                                      const unsigned int* __restrict__ pmax32,
-                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H) {
+                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H,
+                                                     const FineCert* __restrict__ cert) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wlen = nshift - 1 + nfft;
     cplx* xs = (cplx*)smem;                               // window
@@ -674,6 +719,13 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cert) {                                           // fully certified window: the certificate IS the answer
+        const FineCert fc = cert[(size_t)s * H + w];
+        if (fc.a == 0 && fc.b == nshift - 1) {
+            if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; out[(size_t)s * H + w] = o2; }
+            return;
+        }
+    }
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     if (tid == 0) n_items = 0;
     for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
@@ -716,21 +768,8 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
         for (int i = wave; i < ni; i += 4) {
             const int k = items[i] >> 8, c = items[i] & 0xFF;
             const int t0 = c * FS_CHUNK;
-            double ar = 0.0, ai = 0.0;
-            int idx = (int)(((long)k * lane) % nfft);
-            const int stp = (int)(((long)k * 64) % nfft);
-#pragma unroll 4
-            for (int n = lane; n < nfft; n += 64) {
-                const cplx v = xs[t0 + n], t = tw_g[idx];   // L2-resident table, 4 loads in flight
-                ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
-                ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-                idx += stp;
-                if (idx >= nfft) idx -= nfft;
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                ar += __shfl_down(ar, off, 64);
-                ai += __shfl_down(ai, off, 64);
-            }
+            const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
+            const double ar = av.x, ai = av.y;
             if (lane == 0) anchor[i] = make_double2(ar, ai);
         }
         __syncthreads();
@@ -772,6 +811,166 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
             }
         PeakOut o2; o2.p = best; o2.tie = bt; o2.k = bk;
         out[(size_t)s * H + w] = o2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fine_cert: Parseval certificate for the fine search.  grid (H, S), block 256.
+// An FCCH window is dominated by one tone, so the global maximum over (shift, bin) is almost always in
+// the few bins S around the tone (prior = strongest bin of the start window's spectrum x0).  The kernel
+//   1. evaluates the 7 bins S = prior-3..prior+3 exactly (fp64) at all nshift shifts, with the same
+//      anchored sliding as k_fine_verify (direct-DFT anchor at each 64-shift chunk, then the recurrence),
+//      giving P* = max power, its first shift t* and bin k*;
+//   2. bounds every OTHER bin at shift t by Parseval:  P_other(t) <= R(t) = N*E(t) - sum_{k in S} P(t,k),
+//      E(t) = energy of the window starting at t (prefix sums);
+//   3. marks shift t "certified" when R(t)*(1+1e-6) < P*: no bin outside S can reach P* there.
+// Output per window: (P*, t*, k*) and the uncertified range as a prefix [0, a) and a suffix (b, nshift-1].
+// a == 0 and b == nshift-1 means the whole window is certified: (t*, k*) is the exact answer and the
+// prescreen / verify passes skip the window; otherwise they treat it in full.
+// LDS: window | energy prefix | sumS[nshift] | anchors.
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_fine_cert(const StreamState* __restrict__ sts,
+                                                   const cplx* __restrict__ win, long win_stream_stride,
+                                                   long win_stride, int nshift, int nfft,
+                                                   const cplx* __restrict__ tw_g, const cplx* __restrict__ x0,
+                                                   FineCert* __restrict__ cert, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wlen = nshift - 1 + nfft;
+    cplx* xs = (cplx*)smem;                               // window
+    double* pre = (double*)(xs + wlen);                   // pre[i] = sum_{n<i} |x[n]|^2, i = 0..wlen
+    double* sumS = pre + wlen + 1;                        // sum over S of P(t,k), t = 0..nshift-1
+    cplx* anchor = (cplx*)(sumS + ((nshift + 1) & ~1));   // FC_NB * nchunk
+    __shared__ double red_p[4];
+    __shared__ int red_t[4], red_k[4];
+    __shared__ double sh_scan[4];
+    __shared__ int sh_prior, sh_a, sh_b;
+    const int s = blockIdx.y, w = blockIdx.x;
+    if (w >= sts[s].n_win) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    const int nstep = nshift - 1;
+    const int nchunk = (nstep + FC_CHUNK - 1) / FC_CHUNK;
+    for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
+    for (int i = tid; i < nshift; i += 256) sumS[i] = 0.0;
+    if (tid == 0) { sh_a = 0; sh_b = nstep; }
+    // ---- prior: strongest bin of the start window ----
+    {
+        const cplx* x0w = x0 + ((size_t)s * H + w) * nfft;
+        double best = -1.0;
+        int bk = 0;
+        for (int k = tid; k < nfft; k += 256) {
+            const cplx v = x0w[k];
+            const double p = v.x * v.x + v.y * v.y;
+            if (p > best) { best = p; bk = k; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double op = __shfl_down(best, off, 64);
+            const int ok = __shfl_down(bk, off, 64);
+            if (op > best || (op == best && ok < bk)) { best = op; bk = ok; }
+        }
+        if (lane == 0) { red_p[wave] = best; red_k[wave] = bk; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double best = red_p[0];
+        int bk = red_k[0];
+        for (int i = 1; i < 4; ++i)
+            if (red_p[i] > best || (red_p[i] == best && red_k[i] < bk)) { best = red_p[i]; bk = red_k[i]; }
+        sh_prior = bk;
+    }
+    // ---- energy prefix sums: thread i owns elements [i*per, (i+1)*per) ----
+    {
+        const int per = (wlen + 255) / 256;
+        const int i0 = tid * per, i1 = i0 + per < wlen ? i0 + per : wlen;
+        double loc = 0.0;
+        for (int i = i0; i < i1; ++i) loc += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
+        double inc = loc;                                  // inclusive scan across the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) sh_scan[wave] = inc;
+        __syncthreads();
+        double base = inc - loc;
+        for (int i = 0; i < wave; ++i) base += sh_scan[i];
+        double run = base;
+        for (int i = i0; i < i1; ++i) {
+            pre[i] = run;
+            run += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
+        }
+        if (i1 == wlen && i0 < wlen) pre[wlen] = run;
+    }
+    __syncthreads();
+    const int prior = sh_prior;
+    const int nitem = FC_NB * nchunk;
+    // ---- anchors: X_k(64c) by direct DFT, one wave per item ----
+    for (int i = wave; i < nitem; i += 4) {
+        const int j = i / nchunk, c = i - j * nchunk;
+        int k = prior - FC_NB / 2 + j;
+        k = ((k % nfft) + nfft) % nfft;
+        const int t0 = c * FC_CHUNK;
+        const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
+        const double ar = av.x, ai = av.y;
+        if (lane == 0) anchor[i] = make_double2(ar, ai);
+    }
+    __syncthreads();
+    // ---- slides: one lane per (bin, chunk); accumulate sumS, track the first maximum ----
+    double best = -1.0;
+    int bt = 0x7fffffff, bk = 0x7fffffff;
+    for (int i = tid; i < nitem; i += 256) {
+        const int j = i / nchunk, c = i - j * nchunk;
+        int k = prior - FC_NB / 2 + j;
+        k = ((k % nfft) + nfft) % nfft;
+        double wi, wr;
+        sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
+        double xr = anchor[i].x, xi = anchor[i].y;
+        const int t0 = c * FC_CHUNK;
+        if (c == 0) {
+            const double p = xr * xr + xi * xi;
+            atomicAdd(&sumS[0], p);
+            if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
+        }
+        const int lim = nstep - t0 < FC_CHUNK ? nstep - t0 : FC_CHUNK;
+        for (int q = 0; q < lim; ++q) {
+            const cplx a1 = xs[t0 + q + nfft], b1 = xs[t0 + q];
+            const double ar = xr + (a1.x - b1.x), ai = xi + (a1.y - b1.y);
+            xr = ar * wr - ai * wi;
+            xi = ar * wi + ai * wr;
+            const double p = xr * xr + xi * xi;
+            const int m = t0 + q + 1;
+            atomicAdd(&sumS[m], p);
+            if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double op = __shfl_down(best, off, 64);
+        const int ot = __shfl_down(bt, off, 64);
+        const int ok = __shfl_down(bk, off, 64);
+        if (op > best || (op == best && (ot < bt || (ot == bt && ok < bk)))) { best = op; bt = ot; bk = ok; }
+    }
+    if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
+    __syncthreads();
+    best = red_p[0]; bt = red_t[0]; bk = red_k[0];
+    for (int i = 1; i < 4; ++i)
+        if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
+            best = red_p[i]; bt = red_t[i]; bk = red_k[i];
+        }
+    // ---- certificate per shift ----
+    for (int t = tid; t < nshift; t += 256) {
+        const double E = pre[t + nfft] - pre[t];
+        const double R = (double)nfft * E - sumS[t];
+        const bool okc = best > 0.0 && R * 1.000001 < best;
+        if (!okc) {
+            if (t <= bt) atomicMax(&sh_a, t + 1);           // uncertified prefix [0, a)
+            if (t >= bt) atomicMin(&sh_b, t - 1);           // uncertified suffix (b, nstep]
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        FineCert o;
+        o.p = best; o.t = bt; o.k = bk; o.a = sh_a; o.b = sh_b; o.pad = 0;
+        cert[(size_t)s * H + w] = o;
     }
 }
 
