@@ -31,7 +31,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6       # MI355X fp64: vector peak == matrix (MFMA f64) peak
+F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector peak == FP32 (f32-input) MFMA peak
 FLOP_PER_BIN_STEP = 11       # sliding DFT: complex add (2) + complex multiply (6) + |X|^2 (3)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc
 
 
 def parse():
@@ -44,12 +46,16 @@ def parse():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic streams per GPU (tiled to --streams)")
     ap.add_argument("--mode", choices=["table", "stream"], default="table",
                     help="table: ppm table + pos_info only (2 B/sample); stream: also write r_correct (18 B/sample)")
+    ap.add_argument("--workload", choices=["calib", "scan"], default="calib",
+                    help="calib: full FCCH+SCH chain (headline); scan: scanner path of multi_rtl_sdr_gsm_FCCH_scanner.m "
+                         "(front end + FCCH_coarse_position + acceptance; use --frames 64 --streams 200)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU-oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all (otherwise the dominant kernel is bracketed inside the timed region and "
                          "every kernel in a separate untimed pass)")
-    ap.add_argument("--dominant", default="k_fine_search", help="kernel bracketed with HIP events inside the timed region")
+    ap.add_argument("--dominant", default="k_fine_prescreen",
+                    help="kernel bracketed with HIP events inside the timed region")
     return ap.parse_args()
 
 
@@ -77,6 +83,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "scan":
+        return bench_scan(args, rank, world, dev, use_dist)
     D, frames = args.streams, args.frames
     N = frames * synth.FRAME_OV
     fc = 957.4e6                                            # gsm_sync_demod.m:14
@@ -195,28 +203,36 @@ def main():
             n_fine_windows = int(np.sum(det["counts"][:, 1])) * (D // nd) if D % nd == 0 else None
             if n_fine_windows is None:
                 n_fine_windows = int(round(np.mean(det["counts"][:, 1]) * D))
-            if dom == "k_fine_search":
-                flops = n_fine_windows * nfft * nstep * FLOP_PER_BIN_STEP
-                ach = flops / (avg_ms[dom] * 1e-3) / 1e12
-                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": F64_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / F64_PEAK_TFLOPS, 4), "traffic": None,
-                                   "avg_launch_ms": round(avg_ms[dom], 4),
-                                   "note": "fp64 compute roofline: on MI355X the f64 vector peak equals the f64 MFMA peak "
-                                           "(78.6 TFLOP/s); the kernel is an element-wise sliding-DFT recurrence on the "
-                                           "vector ALU (v_fma_f64), not a contraction; flops = fine windows x 1184 bins x "
-                                           "1024 slides x 11"}
-            else:
-                nbytes = D * N * (2 if dom == "k_dc_sum" else 18)
-                ach = nbytes / (avg_ms[dom] * 1e-3) / 1e9
-                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                   "avg_launch_ms": round(avg_ms[dom], 4)}
-            if "k_dc_sum" in avg_ms and avg_ms["k_dc_sum"] > 0:
-                ach = D * N * 2 / (avg_ms["k_dc_sum"] * 1e-3) / 1e9
-                out["roofline_hbm_stream_kernel"] = {"kernel": "k_dc_sum", "bound": "hbm", "achieved": round(ach, 1),
-                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                                     "avg_launch_ms": round(avg_ms["k_dc_sum"], 5)}
+            traffic = {}
+            if os.path.exists(PMC_FILE):
+                with open(PMC_FILE) as f:
+                    pmc = json.load(f)
+                if pmc.get("streams_per_gpu") == D and pmc.get("samples_per_stream") == N:
+                    traffic = pmc.get("hbm_bytes_per_launch", {})
+            sliding_flops = n_fine_windows * nfft * nstep * FLOP_PER_BIN_STEP
+            models = {   # kernel -> (bound, algorithmic work per launch, peak, unit, note)
+                "k_fine_prescreen": ("mfma", sliding_flops / 1e12, F32_PEAK_TFLOPS, "TFLOP/s",
+                                     "fp32 compute roofline (MI355X f32 vector peak == f32-input MFMA peak, 157.3 TFLOP/s); "
+                                     "element-wise sliding-DFT recurrence on the vector ALU (v_pk_fma_f32), not a "
+                                     "contraction; flops = fine windows x 1184 bins x 1024 slides x 11"),
+                "k_fine_search": ("mfma", sliding_flops / 1e12, F64_PEAK_TFLOPS, "TFLOP/s",
+                                  "fp64 compute roofline (f64 vector peak == f64 MFMA peak, 78.6 TFLOP/s); all-bins "
+                                  "fp64 sliding DFT (GSMCAL_PRESCREEN=0)"),
+                "k_front_fused": ("hbm", D * N * 2.25 / 1e9, HBM_PEAK_GBS, "GB/s",
+                                  "2 B/sample raw read + 16/64 B/sample decimated complex-double write"),
+            }
+
+            def roof(kernel):
+                bound, work, peak, unit, note = models[kernel]
+                ach = work / (avg_ms[kernel] * 1e-3)
+                return {"kernel": kernel, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "traffic": traffic.get(kernel),
+                        "avg_launch_ms": round(avg_ms[kernel], 5), "note": note}
+
+            if dom in models:
+                out["roofline"] = roof(dom)
+            if "k_front_fused" in avg_ms and dom != "k_front_fused":
+                out["roofline_hbm_stream_kernel"] = roof("k_front_fused")
         # ---- CPU baseline: the oracle (fp64 NumPy/SciPy restatement) on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import gsmcal_oracle as oracle
@@ -242,6 +258,79 @@ def main():
     if use_dist:
         if rank == 0 and gathered is not None:
             assert torch.equal(gathered[:D], table_t), "all-gathered table differs from the local rows"
+        dist.destroy_process_group()
+
+
+def bench_scan(args, rank, world, dev, use_dist):
+    """Scanner path (BASELINE configs 3/5): D captures resident in HBM -> snr, num_hit per capture."""
+    import torch
+    import torch.distributed as dist
+
+    import gsmcal
+    from gsmcal import synth
+    D, frames = args.streams, args.frames
+    N = frames * synth.FRAME_OV
+    coef = np.ascontiguousarray(synth.fir1(30, 200e3 / synth.FS))     # multi_rtl_sdr_gsm_FCCH_scanner.m:53
+    nd = max(1, min(args.distinct, D))
+    distinct = np.stack([synth.make_stream(dongle=1000 + rank, arfcn=i, num_frames=frames, bcch=(i % 4 != 3))[0]
+                         for i in range(nd)])
+    raw = np.ascontiguousarray(np.tile(distinct, ((D + nd - 1) // nd, 1))[:D])
+    raw_t = torch.from_numpy(raw).to(dev)
+    out_t = torch.zeros((D, 2), dtype=torch.float64, device=dev)
+    gathered = torch.zeros((world * D, 2), dtype=torch.float64, device=dev) if use_dist else None
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = gsmcal.Context(int(os.environ.get("LOCAL_RANK", "0")), stream=stream.cuda_stream)
+    cp = coef.ctypes.data_as(gsmcal._lib.c_double_p)
+
+    def step():
+        ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
+                                                     C.c_void_p(out_t.data_ptr()), None, None, None), "scan")
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, out_t)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    res = out_t.cpu().numpy()
+    value = world * D * N * args.steps / elapsed / 1e6
+    out = {"metric": "IQ Msamples/s through FCCH scanner path", "value": round(value, 3), "unit": "Msample/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": f"synthetic GSM uint8 IQ, {nd} distinct captures tiled to {D} (3 of 4 carry a BCCH carrier)",
+           "config": {"workload": f"scanner path multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,164-185: {D} captures/GPU x {N} "
+                                  f"IQ samples ({frames} frames), fir1(30)", "captures_per_gpu": D,
+                      "captures_with_hits": int(np.sum(res[:, 1] > 0)), "bytes_per_sample_algorithmic": 2.25},
+           "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1)}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import gsmcal_oracle as oracle
+            t_cpu, done = 0.0, 0
+            while t_cpu < args.cpu_seconds and done < nd:
+                c0 = time.perf_counter()
+                o = oracle.scan_capture(distinct[done], coef)
+                t_cpu += time.perf_counter() - c0
+                assert o["num_hit"] == res[done, 1] and abs(o["snr"] - res[done, 0]) < 1e-8, "scan parity"
+                done += 1
+            out["cpu_baseline"] = {"value": round(done * N / t_cpu / 1e6, 4), "unit": "Msample/s", "cores": 1, "kind": "port",
+                                   "sample": f"{done} captures through oracle.scan_capture in {t_cpu:.1f} s"}
+        print(json.dumps(out))
+    if use_dist:
         dist.destroy_process_group()
 
 
