@@ -439,6 +439,9 @@ def SCH_corr_rate_correction(s, FCCH_pos, sch_training_sequence, oversampling_ra
         max_idx = int(np.argmax(corr_val)) + 1
         SCH_pos[i] = sp + max_idx - 1
         if max_idx == 1 or max_idx == length:  # :59
+            if info is not None:   # the reference returns here; keep what was computed so far for the tests
+                info["first_round_sch_pos"] = SCH_pos[:i + 1].copy()
+                info["sch_edge_abort"] = True
             return np.array([[-1.0, -1.0]]), r, sampling_ppm
     if info is not None:
         info["first_round_sch_pos"] = SCH_pos.copy()
@@ -572,6 +575,7 @@ def calibrate_stream(raw, coef, sch_training_sequence, carrier_freq,
     info2 = {}
     pos_info, r_c, sp2 = SCH_corr_rate_correction(r_c, FCCH_pos, sch_training_sequence, oversampling_ratio, info2)  # :119
     out["sch_first_round_pos"] = info2.get("first_round_sch_pos", np.zeros(0))
+    out["sch_edge_abort"] = bool(info2.get("sch_edge_abort", False))
     out["pos_info"] = pos_info
     r_c, cp2 = carrier_correct_post_SCH(r_c, pos_info, oversampling_ratio, carrier_freq)  # :120
     out["sampling_ppm"] = np.array([sp1, sp2])

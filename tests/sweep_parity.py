@@ -1,0 +1,79 @@
+"""Randomised parity sweep (not collected by pytest): N seeded streams through the HIP batch path and the
+oracle; prints mismatches.  Usage: python tests/sweep_parity.py [n_streams] [first_dongle] [frames]"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+FC = 957.4e6
+
+
+def _oracle_one(args):
+    d, frames, kw = args
+    import gsmcal
+    from oracle import gsmcal_oracle as o
+    synth = gsmcal.synth
+    raw, _ = synth.make_stream(dongle=d, num_frames=frames, **kw)
+    coef = o.fir1(46, 200e3 / synth.FS)
+    try:
+        return d, o.calibrate_stream(raw, coef, synth.sch_training_sequence(), FC), None
+    except o.MatlabIndexError as e:
+        return d, None, str(e)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    frames = int(sys.argv[3]) if len(sys.argv) > 3 else 102
+    import gsmcal
+    import parity
+    synth = gsmcal.synth
+    coef = synth.fir1(46, 200e3 / synth.FS)
+    ts = synth.sch_training_sequence()
+    rng = np.random.default_rng(first)
+    kws = []
+    for i in range(n):   # widen the distribution: low SNR, larger ppm, occasional non-BCCH carrier
+        kw = {}
+        if i % 5 == 1:
+            kw["snr_db"] = float(rng.uniform(5, 15))
+        if i % 7 == 2:
+            kw["sampling_ppm"] = float(rng.uniform(-300, 300))
+        if i % 11 == 3:
+            kw["bcch"] = False
+        if i % 13 == 4:
+            kw["carrier_ppm"] = float(rng.uniform(-60, 60))
+        kws.append(kw)
+    t0 = time.time()
+    raws = [synth.make_stream(dongle=first + i, num_frames=frames, **kws[i])[0] for i in range(n)]
+    raw = np.stack(raws)
+    out = gsmcal.calibrate_batch(raw, coef, ts, FC)
+    det = gsmcal.last_batch_details(n)
+    t1 = time.time()
+    with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(_oracle_one, [(first + i, frames, kws[i]) for i in range(n)]))
+    bad = 0
+    n_ok = 0
+    for i, (d, orc, err) in enumerate(res):
+        if orc is None:
+            if out["table"][i, 9] >= 0:
+                bad += 1
+                print(f"stream {d}: oracle raised '{err}' but gpu status {out['table'][i, 9]}")
+            continue
+        try:
+            parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+            n_ok += out["table"][i, 9] == 0
+        except AssertionError as e:
+            bad += 1
+            print(f"stream {d} {kws[i]}: MISMATCH {e}")
+    print(f"sweep: {n} streams, {n_ok} calibrated, {bad} mismatches; gpu+gen {t1 - t0:.1f}s oracle {time.time() - t1:.1f}s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -325,3 +325,29 @@ def test_full_size_batch_properties(g, setup):
     orc = o.calibrate_stream(distinct[ok[0]], setup["coef"], setup["ts"], FC)
     parity.assert_ppm(singles["table"][ok[0], 4], orc["total_sampling_ppm"], "total sampling ppm")
     parity.assert_ppm(singles["table"][ok[0], 5], orc["total_carrier_ppm"], "total carrier ppm")
+
+
+def test_randomised_sweep_against_oracle(g, setup):
+    """48 seeded streams with a widened distribution (low SNR, large sampling error, non-BCCH carriers): every
+    position bit-exact, ppm within 1e-6 (tests/sweep_parity.py runs the same comparison on hundreds of streams)."""
+    rng = np.random.default_rng(77)
+    n = 48
+    kws = []
+    for i in range(n):
+        kw = {}
+        if i % 5 == 1:
+            kw["snr_db"] = float(rng.uniform(5, 15))
+        if i % 7 == 2:
+            kw["sampling_ppm"] = float(rng.uniform(-300, 300))
+        if i % 11 == 3:
+            kw["bcch"] = False
+        kws.append(kw)
+    raw = np.stack([g.synth.make_stream(dongle=700 + i, **kws[i])[0] for i in range(n)])
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    det = g.last_batch_details(n)
+    calibrated = 0
+    for i in range(n):
+        orc = o.calibrate_stream(raw[i], setup["coef"], setup["ts"], FC)
+        parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+        calibrated += out["table"][i, 9] == 0
+    assert calibrated >= n // 2
