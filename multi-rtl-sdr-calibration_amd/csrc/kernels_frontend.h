@@ -13,6 +13,18 @@
 
 typedef double2 cplx;
 
+// sin/cos of a LARGE fp64 argument t (|t| up to ~1e6 rad: t = k*comp_phase_rotate, k up to 1e6) with the
+// accuracy of a correctly reduced argument, several times cheaper than the library's general path:
+// n = round(t/2pi); y = t - n*2pi with 2pi = C1 + C2 split so that the first fma is EXACT (t and n*C1 are
+// both multiples of 2^-50 and the difference is < 8, so it fits a double), the second adds n*C2 <= 4e-11
+// with an error <= ulp(y); then the library routine on |y| <= pi (its cheap small-argument path).
+__device__ __forceinline__ void sincos_large(double t, double* sn, double* cs) {
+    const double n = rint(t * 0.15915494309189535);            // 1/(2*pi)
+    double y = fma(-n, 6.28318530717958623e+00, t);            // C1 = fl(2*pi)
+    y = fma(-n, 2.44929359829470641e-16, y);                   // C2 = 2*pi - C1
+    sincos(y, sn, cs);
+}
+
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -490,7 +502,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             for (int i = threadIdx.x; i < cnt; i += NT) {
                 const long k = lo[j] + i;
                 double sn, cs;
-                sincos((double)k * p, &sn, &cs);            // exp(1i*(0:len-1)'*comp_phase_rotate)
+                sincos_large((double)k * p, &sn, &cs);      // exp(1i*(0:len-1)'*comp_phase_rotate): k*p rounded once
                 o[i] = cmul(src[i], make_double2(cs, sn));
             }
         } else {
