@@ -42,7 +42,8 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert;
+    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert, partial;
+    int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
 };
@@ -446,23 +447,29 @@ int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const doub
     const long nd = (n + decim - 1) / decim;
     const size_t span = (size_t)256 * decim + ntaps + 24;
     const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
-    if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
+    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
     LAUNCH(c, k_fir_decim_raw, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
            (const StreamState*)c->cur->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
     CHECK_LAUNCH(c);
     return 0;
 }
 
-// batch front end: one pass over the raw bytes (sums + FIR of the raw samples), then the means
+// batch front end: one pass over the raw bytes (per-block byte sums + FIR of the raw samples).  The means are
+// formed from the partial sums by the coarse kernels, and k_coarse_scan builds each stream's state from scratch,
+// so the batch path needs neither a memset of the state array nor a separate mean kernel.
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                 cplx* d_out, long out_stride) {
     const long nd = (n + decim - 1) / decim;
     const size_t span = (size_t)256 * decim + ntaps + 24;
     const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
-    if (lds > 160 * 1024) return GSMCAL_E_UNSUPPORTED;
-    LAUNCH(c, k_front_fused, dim3((unsigned)((nd + 255) / 256), S), dim3(256), lds, d_raw, 2 * n,
-           (StreamState*)c->cur->state.p, d_coef, ntaps, decim, nd, d_out, out_stride);
-    LAUNCH(c, k_finish_mean, dim3((S + 63) / 64), dim3(64), 0, (StreamState*)c->cur->state.p, S, n);
+    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
+    const unsigned nblk = (unsigned)((nd + 255) / 256);
+    RET_IF(ensure(c, c->cur->state, (size_t)S * sizeof(StreamState)));
+    RET_IF(ensure(c, c->cur->partial, (size_t)S * nblk * 2 * sizeof(unsigned long long)));
+    c->cur->npartial = (int)nblk;
+    c->last_S = S;
+    LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef,
+           ntaps, decim, nd, d_out, out_stride);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -479,12 +486,14 @@ size_t coarse_scan_lds(long nwin, int mv_len) {
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
-           bool mean_corr = false) {
+           bool mean_corr = false, long n0 = 0) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
     if (mean_corr) {   // input = FIR of the raw bytes (front_fused): DC removed on load
         a.mean_corr = 1;
-        a.sts_mean = (const StreamState*)c->cur->state.p;
+        a.partial = (const unsigned long long*)c->cur->partial.p;
+        a.npartial = c->cur->npartial;
+        a.n0 = n0;
         double cs = 0.0;
         for (double v : c->h_coef) cs += v;
         a.csum_all = cs;
@@ -661,16 +670,17 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (hipSetDevice(device_id) != hipSuccess) return GSMCAL_E_HIP;
     // kernels whose dynamic LDS may exceed the 64 KiB default
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_cert, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipGetLastError();   // an attribute request the device rejects must not surface at the first launch
     gsmcal_ctx* c = new gsmcal_ctx();
     c->device = device_id;
     c->stream = (hipStream_t)hip_stream;
@@ -714,7 +724,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert, &L.partial};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1137,9 +1147,8 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const int lo = L.lo, S = L.n;
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
-        RET_IF(init_states(c, S, n));
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
@@ -1212,9 +1221,8 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const int lo = L.lo, S = L.n;
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
-        RET_IF(init_states(c, S, n));
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true));            // :117 (+ fine window setup)
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n));         // :117 (+ state init, fine setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;
         RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts));                              // :118 (+ SCH window setup)

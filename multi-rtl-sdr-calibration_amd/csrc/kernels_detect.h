@@ -141,8 +141,30 @@ struct CoarseArgs {
     unsigned long long* dbg;                  // optional: 8 timestamps per stream (development aid)
     double csum_all, csum_first;              // > 0 taps: the input is the FIR of the raw bytes; remove mean*csum on load
     int mean_corr;
-    const StreamState* sts_mean;              // per-stream means (k_coarse_snr has no other use for the state)
+    const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
+    int npartial; long n0;                    //            and the capture length they divide by
 };
+
+// raw2iq.m:8 from the front kernel's per-block partial sums: exact integer totals, one fp64 divide each
+// (block-cooperative: wave 0 adds the partials, the totals are shared through LDS; contains a barrier)
+__device__ __forceinline__ void stream_mean(const CoarseArgs& a, int stream, double* mr, double* mi,
+                                            unsigned long long* tot_i, unsigned long long* tot_q) {
+    __shared__ unsigned long long sh_tot[2];
+    if (threadIdx.x < 64) {
+        unsigned long long si = 0, sq = 0;
+        const unsigned long long* p = a.partial + (size_t)stream * a.npartial * 2;
+        for (int b = threadIdx.x; b < a.npartial; b += 64) { si += p[2 * b]; sq += p[2 * b + 1]; }
+        for (int off = 32; off > 0; off >>= 1) {
+            si += __shfl_down(si, off, 64);
+            sq += __shfl_down(sq, off, 64);
+        }
+        if (threadIdx.x == 0) { sh_tot[0] = si; sh_tot[1] = sq; }
+    }
+    __syncthreads();
+    *tot_i = sh_tot[0]; *tot_q = sh_tot[1];
+    *mr = (double)sh_tot[0] / (double)a.n0;
+    *mi = (double)sh_tot[1] / (double)a.n0;
+}
 
 __device__ __forceinline__ DecView dec_view(const CoarseArgs& a, int stream, double mean_re, double mean_im) {
     DecView v;
@@ -189,8 +211,9 @@ __global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.nwin) return;
-    const DecView s = a.mean_corr ? dec_view(a, blockIdx.y, a.sts_mean[blockIdx.y].mean_re, a.sts_mean[blockIdx.y].mean_im)
-                                  : dec_view(a, blockIdx.y, 0.0, 0.0);
+    double mr = 0.0, mi = 0.0;
+    if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }
+    const DecView s = dec_view(a, blockIdx.y, mr, mi);
     a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s, i, g.fft_len, tw);
 }
 
@@ -214,7 +237,10 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
     double* snr_s = (double*)(tw + 64);
     StreamState* st_g = sts + blockIdx.x;
-    const DecView s = dec_view(a, blockIdx.x, st_g->mean_re, st_g->mean_im);
+    double mr0 = 0.0, mi0 = 0.0;
+    unsigned long long ti0 = 0, tq0 = 0;
+    if (a.mean_corr) stream_mean(a, blockIdx.x, &mr0, &mi0, &ti0, &tq0);      // batch path: means from the front kernel
+    const DecView s = dec_view(a, blockIdx.x, a.mean_corr ? mr0 : st_g->mean_re, a.mean_corr ? mi0 : st_g->mean_im);
     const long len = a.len;
     const CoarseGeom g = coarse_geom(a);
     const int fft_len = g.fft_len, mv_len = g.mv_len;
@@ -222,7 +248,21 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     const int tid = threadIdx.x;
 #define CS_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
     CS_STAMP(0);
-    {
+    if (a.mean_corr) {
+        // batch path: this kernel is the first to touch the stream's state -- build it from scratch in LDS (all zero,
+        // then the sentinels the reference functions start from), no memset / finish-mean launches needed
+        uint4* dst = (uint4*)st;
+        for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        if (tid == 0) {
+            st->n0 = a.n0;
+            st->sum_i = ti0; st->sum_q = tq0;
+            st->mean_re = mr0; st->mean_im = mi0;
+            st->sampling_ppm1 = INFINITY; st->carrier_ppm1 = INFINITY;
+            st->sampling_ppm2 = INFINITY; st->carrier_ppm2 = INFINITY;
+            st->fcch_is_sentinel = 1;
+        }
+    } else {
         const uint4* src = (const uint4*)st_g;
         uint4* dst = (uint4*)st;
         for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];

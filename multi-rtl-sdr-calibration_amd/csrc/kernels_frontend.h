@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // k_front_fused: ONE pass over the raw bytes for the batch paths.  Per block of 256 kept rows it
-//   (1) adds the bytes of its own decim*256 samples to the stream's exact integer I/Q sums (raw2iq.m:8),
+//   (1) writes the exact integer I/Q byte sums of its own decim*256 samples (raw2iq.m:8) as a per-block partial,
 //   (2) writes y'[j] = sum_k coef[k]*raw[j*decim-k] for its rows -- the FIR of the RAW samples.
 // The detector subtracts mean*sum(coef) on load (DecView in kernels_detect.h): filter() is linear, so
 // y = y' - mean*sum_{valid k} coef[k]; this differs from filtering (raw-mean) only in fp64 rounding
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
 // grid (ceil(nd/256), S), block 256.  LDS as k_fir_decim_raw.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__ raw, long stream_bytes,
-                                                     StreamState* __restrict__ st,
+                                                     unsigned long long* __restrict__ partial,
                                                      const double* __restrict__ coef, int ntaps,
                                                      int decim, long nd, cplx* __restrict__ out,
                                                      long out_stride) {
@@ -281,17 +281,20 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
         }
     }
     {
+        __shared__ unsigned long long sh_sum[8];
         unsigned long long ti = si, tq = sq;
         for (int off = 32; off > 0; off >>= 1) {
             ti += __shfl_down(ti, off, 64);
             tq += __shfl_down(tq, off, 64);
         }
-        if ((t & 63) == 0) {
-            atomicAdd(&st[s].sum_i, ti);
-            atomicAdd(&st[s].sum_q, tq);
+        if ((t & 63) == 0) { sh_sum[2 * (t >> 6)] = ti; sh_sum[2 * (t >> 6) + 1] = tq; }
+        __syncthreads();
+        if (t == 0) {     // this block's exact byte sums; consumers add the gridDim.x partials (integers: any order)
+            unsigned long long* p = partial + ((size_t)s * gridDim.x + blockIdx.x) * 2;
+            p[0] = sh_sum[0] + sh_sum[2] + sh_sum[4] + sh_sum[6];
+            p[1] = sh_sum[1] + sh_sum[3] + sh_sum[5] + sh_sum[7];
         }
     }
-    __syncthreads();
     // (2) FIR of the raw samples, oldest tap first
     if (t >= jn) return;
     const long i_out = (j0 + t) * decim;
