@@ -55,7 +55,7 @@ struct gsmcal_ctx {
     std::string err;
     Lane lanes[MAX_LANES];
     Lane* cur = nullptr;        // lane the helpers below enqueue on
-    int n_lanes_cfg = 1;        // GSMCAL_LANES (multi-lane dispatch is kept for experiments)
+    int n_lanes_cfg = 2;        // GSMCAL_LANES: upper bound; a lane gets at least 64 streams (measured: 2 lanes help from 128 streams on)
     int n_lanes_used = 1;
     const double* cf_lane = nullptr;   // carrier_freq of the current lane's first stream (batch path)
     hipEvent_t fork = nullptr;
@@ -565,7 +565,7 @@ int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
 // Split d units over the lanes: returns the number of lanes used and fills lo/n per lane.
 int plan_lanes(gsmcal_ctx* c, int d) {
     int nl = c->n_lanes_cfg;
-    if (nl > d / 8) nl = d / 8;          // keep at least 8 streams per lane
+    if (nl > d / 64) nl = d / 64;        // at least 64 streams per lane: below that splitting only adds launches
     if (nl < 1) nl = 1;
     for (int i = 0; i < nl; ++i) {
         c->lanes[i].lo = (int)(((long)i * d) / nl);
