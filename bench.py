@@ -95,8 +95,7 @@ def main():
     # ---- synthetic input, resident in HBM before the timed region ----
     nd = max(1, min(args.distinct, D))
     distinct = np.stack([synth.make_stream(dongle=rank * D + i, num_frames=frames)[0] for i in range(nd)])
-    raw = np.ascontiguousarray(np.tile(distinct, ((D + nd - 1) // nd, 1))[:D])
-    raw_t = torch.from_numpy(raw).to(dev)
+    raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device
     table_t = torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev)
     pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
     rlen_t = torch.zeros((D,), dtype=torch.int64, device=dev)
@@ -274,8 +273,7 @@ def bench_scan(args, rank, world, dev, use_dist):
     nd = max(1, min(args.distinct, D))
     distinct = np.stack([synth.make_stream(dongle=1000 + rank, arfcn=i, num_frames=frames, bcch=(i % 4 != 3))[0]
                          for i in range(nd)])
-    raw = np.ascontiguousarray(np.tile(distinct, ((D + nd - 1) // nd, 1))[:D])
-    raw_t = torch.from_numpy(raw).to(dev)
+    raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device
     out_t = torch.zeros((D, 2), dtype=torch.float64, device=dev)
     gathered = torch.zeros((world * D, 2), dtype=torch.float64, device=dev) if use_dist else None
     stream = torch.cuda.Stream(device=dev)

@@ -468,8 +468,10 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
     RET_IF(ensure(c, c->cur->partial, (size_t)S * nblk * 2 * sizeof(unsigned long long)));
     c->cur->npartial = (int)nblk;
     c->last_S = S;
+    bool sym = (int)c->h_coef.size() == ntaps;                 // linear-phase taps? (fir1 and the .fda designs are)
+    for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
     LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef,
-           ntaps, decim, nd, d_out, out_stride);
+           ntaps, decim, nd, d_out, out_stride, sym ? 1 : 0);
     CHECK_LAUNCH(c);
     return 0;
 }

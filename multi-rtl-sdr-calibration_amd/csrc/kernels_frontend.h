@@ -196,17 +196,21 @@ __global__ void __launch_bounds__(256) k_fir_decim_raw(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // k_front_fused: ONE pass over the raw bytes for the batch paths.  Per block of 256 kept rows it
 //   (1) writes the exact integer I/Q byte sums of its own decim*256 samples (raw2iq.m:8) as a per-block partial,
-//   (2) writes y'[j] = sum_k coef[k]*raw[j*decim-k] for its rows -- the FIR of the RAW samples.
+//   (2) writes y'[j] = sum_k coef[k]*raw[j*decim-k] for its rows -- the FIR of the RAW samples (for
+//       linear-phase taps the two samples sharing a tap are added as integers first).
 // The detector subtracts mean*sum(coef) on load (DecView in kernels_detect.h): filter() is linear, so
 // y = y' - mean*sum_{valid k} coef[k]; this differs from filtering (raw-mean) only in fp64 rounding
 // (~1e-15 relative) and feeds nothing but the FCCH coarse detector's threshold decisions.
 // grid (ceil(nd/256), S), block 256.  LDS as k_fir_decim_raw.
 // ------------------------------------------------------------------------------------------------
+#ifndef FF_INFLIGHT
+#define FF_INFLIGHT 8
+#endif
 __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__ raw, long stream_bytes,
                                                      unsigned long long* __restrict__ partial,
                                                      const double* __restrict__ coef, int ntaps,
                                                      int decim, long nd, cplx* __restrict__ out,
-                                                     long out_stride) {
+                                                     long out_stride, int symmetric) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* c_s = (double*)smem;
     unsigned short* r_s = (unsigned short*)(smem + ((ntaps * 8 + 15) & ~15));
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
     const int span = (int)(last - first + 1);
     for (int i = threadIdx.x; i < ntaps; i += 256) c_s[i] = coef[i];
     const int t = threadIdx.x;
-    // stage [first, first+span) into LDS with 16-byte loads, four in flight per lane, and take the integer
+    // stage [first, first+span) into LDS with 16-byte loads, FF_INFLIGHT in flight per lane, and take the integer
     // I/Q sums (raw2iq.m:8) of the owned samples straight from the registers (v_sad_u8)
     const long ao = (long)(((uintptr_t)base >> 1) & 7);
     long mm = (first + ao) % 8;
@@ -234,10 +238,10 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
     const int nchunk = (int)((first + span - first_al + 7) >> 3);
     const long o0 = j0 * decim;
     unsigned int si = 0, sq = 0;
-    for (int c0 = t; c0 < nchunk; c0 += 1024) {
-        uint4 v[4];
+    for (int c0 = t; c0 < nchunk; c0 += 256 * FF_INFLIGHT) {
+        uint4 v[FF_INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FF_INFLIGHT; ++u) {
             const int c = c0 + 256 * u;
             const long g0 = first_al + 8L * c;
             v[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FF_INFLIGHT; ++u) {
             const int c = c0 + 256 * u;
             if (c >= nchunk) continue;
             const long g0 = first_al + 8L * c;
@@ -295,17 +299,36 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
             p[1] = sh_sum[1] + sh_sum[3] + sh_sum[5] + sh_sum[7];
         }
     }
-    // (2) FIR of the raw samples, oldest tap first
+    // (2) FIR of the raw samples
     if (t >= jn) return;
     const long i_out = (j0 + t) * decim;
     double ar = 0.0, ai = 0.0;
-    for (int k = ntaps - 1; k >= 0; --k) {
-        const long g = i_out - k;
-        if (g < 0) continue;                                 // zero initial state
-        const unsigned short v = r_s[lds_pad((int)(g - first_al))];
-        const double c = c_s[k];
-        ar = fma(c, (double)(v & 0xFF), ar);
-        ai = fma(c, (double)(v >> 8), ai);
+    if (symmetric && i_out >= ntaps - 1) {
+        // linear-phase taps (coef[k] == coef[ntaps-1-k], checked on the host): add the two samples that share a
+        // tap as INTEGERS first (exact), then one conversion and one FMA per pair -- half the fp64 work
+        const int base = (int)(i_out - (ntaps - 1) - first_al);          // oldest sample of this output
+        const int half = ntaps >> 1;
+#pragma unroll 8
+        for (int k = 0; k < half; ++k) {                 // unrolled: 16 independent LDS reads in flight
+            const unsigned a = r_s[lds_pad(base + k)], b = r_s[lds_pad(base + ntaps - 1 - k)];
+            const double c = c_s[k];
+            ar = fma(c, (double)((a & 0xFF) + (b & 0xFF)), ar);
+            ai = fma(c, (double)((a >> 8) + (b >> 8)), ai);
+        }
+        if (ntaps & 1) {
+            const unsigned a = r_s[lds_pad(base + half)];
+            ar = fma(c_s[half], (double)(a & 0xFF), ar);
+            ai = fma(c_s[half], (double)(a >> 8), ai);
+        }
+    } else {
+        for (int k = ntaps - 1; k >= 0; --k) {                   // oldest tap first; zero initial state
+            const long g = i_out - k;
+            if (g < 0) continue;
+            const unsigned short v = r_s[lds_pad((int)(g - first_al))];
+            const double c = c_s[k];
+            ar = fma(c, (double)(v & 0xFF), ar);
+            ai = fma(c, (double)(v >> 8), ai);
+        }
     }
     out[(size_t)s * out_stride + j0 + t] = make_double2(ar, ai);
 }
