@@ -42,7 +42,7 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert, partial;
+    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert, fclo, partial;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
@@ -70,8 +70,7 @@ struct gsmcal_ctx {
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
-    bool certify = false;           // GSMCAL_CERT=1: Parseval certificate before the prescreen (experiment: exact, but the
-                                    // certificate kernel currently costs more than the prescreen work it saves)
+    bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, the prescreen sweeps every window in full
     bool capturing = false;
     // shared workspace
     DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;
@@ -288,9 +287,16 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
+    // Parseval certificate (k_fine_cert): settles most windows outright and leaves the all-bin sweep a short prefix
+    const int fc_thr = fc_threads(g.fine_nshift);
+    const size_t clds = (fc_lds_bytes(g.fine_nshift, g.nfft) + 15) & ~(size_t)15;
+    const bool use_cert = c->prescreen && c->certify && fc_thr <= 512 && clds <= 159 * 1024 &&
+                          (g.fine_nshift - 1) % FS_CHUNK == 0 && g.nfft >= 2 * FC_NB;
+    if (use_cert) RET_IF(ensure(c, c->cur->fclo, (size_t)S * H * sizeof(int)));
     LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
            wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H,
-           c->prescreen ? (unsigned int*)c->cur->pmax32.p : (unsigned int*)nullptr);
+           c->prescreen ? (unsigned int*)c->cur->pmax32.p : (unsigned int*)nullptr,
+           use_cert ? (int*)c->cur->fclo.p : (int*)nullptr);
     StepArgs sa_fine = sa;
     if (c->prescreen) {
         // two-pass fine search: packed-fp32 prescreen of every (bin, shift), exact fp64 on the candidates only
@@ -299,13 +305,10 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
         RET_IF(ensure(c, c->cur->esum, (size_t)S * H * sizeof(double)));
         const FineCert* certp = nullptr;
-        if (c->certify) {
+        if (use_cert) {
             RET_IF(ensure(c, c->cur->cert, (size_t)S * H * sizeof(FineCert)));
-            const int nchunk = (g.fine_nshift - 1 + FC_CHUNK - 1) / FC_CHUNK;
-            const size_t clds = ((size_t)g.fine_wlen * sizeof(cplx) + (size_t)(g.fine_wlen + 2) * sizeof(double) +
-                                 (size_t)(g.fine_nshift + 2) * sizeof(double) + (size_t)FC_NB * nchunk * sizeof(cplx) + 15) & ~(size_t)15;
-            LAUNCH(c, k_fine_cert, dim3(H, S), dim3(256), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const cplx*)c->cur->x0.p, (FineCert*)c->cur->cert.p, H);
+            LAUNCH(c, k_fine_cert, dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const int*)c->cur->fclo.p, (FineCert*)c->cur->cert.p, H);
             certp = (const FineCert*)c->cur->cert.p;
         }
         const int nbp = (g.nfft / 2 + 255) / 256;          // two bins per lane
@@ -326,6 +329,25 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
                (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
                peaks, H, g.NB);
+    }
+    if (c->prescreen && getenv("GSMCAL_DBG_CERT") && c->cur->cert.p) {   // histogram of the certificate's open chunks
+        (void)hipStreamSynchronize(c->cur->stream);
+        std::vector<FineCert> hc((size_t)S * H);
+        std::vector<StreamState> hs(S);
+        (void)hipMemcpy(hc.data(), c->cur->cert.p, hc.size() * sizeof(FineCert), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs.data(), st, (size_t)S * sizeof(StreamState), hipMemcpyDeviceToHost);
+        int hist[34] = {0}, nw = 0;
+        for (int s = 0; s < S; ++s)
+            for (int w = 0; w < hs[s].n_win && w < H; ++w) {
+                const FineCert& f = hc[(size_t)s * H + w];
+                ++hist[f.nch < 0 ? 33 : (f.nch > 32 ? 32 : f.nch)];
+                ++nw;
+                if (getenv("GSMCAL_DBG_CERT")[0] == '2')
+                    fprintf(stderr, "cert s=%d w=%d p=%.6g t=%d k=%d a=%d b=%d nch=%d\n", s, w, f.p, f.t, f.k, f.a, f.b, f.nch);
+            }
+        fprintf(stderr, "fine cert: %d windows; open chunks histogram:", nw);
+        for (int i = 0; i < 34; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+        fprintf(stderr, "\n");
     }
     LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa_fine, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
@@ -726,7 +748,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert, &L.partial};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert, &L.fclo, &L.partial};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);

@@ -501,13 +501,14 @@ __global__ void k_make_twiddles(cplx* tw, int n) {
 }
 
 #define FFT_THREADS 512
+#define FC_NB 8        /* k_fine_cert: candidate bins around the tone */
 template <int MODE>
 __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __restrict__ sts,
                                                            const cplx* __restrict__ win, long win_stream_stride,
                                                            long win_stride, int nfft,
                                                            const cplx* __restrict__ tw_g, PeakOut* __restrict__ peaks,
                                                            cplx* __restrict__ x0, int H,
-                                                           unsigned int* __restrict__ pmax32) {
+                                                           unsigned int* __restrict__ pmax32, int* __restrict__ fc_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N2 = nfft / 37;
     const int ldb = N2 + 1;                     // padded row: conflict-free column reads in step 2
@@ -534,13 +535,15 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
         const double ar = X.x, ai = X.y;
         if (MODE == 1) {
             x0[((size_t)s * H + w) * nfft + k] = make_double2(ar, ai);
+            const double p = ar * ar + ai * ai;
+            if (p > best) { best = p; key = k; kk = k; }     // (ascending k per thread: first maximum)
         } else {
             const double p = ar * ar + ai * ai;
             const int sk = (k + nfft / 2) % nfft;            // position after fftshift
             if (p > best || (p == best && sk < key)) { best = p; key = sk; kk = k; }
         }
     }
-    if (MODE == 1) return;
+    if (MODE == 1 && !fc_lo) return;
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(best, off, 64);
         const int ok = __shfl_down(key, off, 64);
@@ -553,6 +556,14 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
     if (tid == 0) {
         for (int i = 1; i < FFT_THREADS / 64; ++i)
             if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; kk = red_k[i]; }
+        if (MODE == 1) {
+            // k_fine_cert's bins: the FC_NB around the strongest bin of the start window, leaning to its stronger side
+            const cplx u = fft37_step2_bin(B, wN2, N2, ldb, (kk + 1) % nfft);
+            const cplx d = fft37_step2_bin(B, wN2, N2, ldb, (kk + nfft - 1) % nfft);
+            const bool up = u.x * u.x + u.y * u.y > d.x * d.x + d.y * d.y;
+            fc_lo[(size_t)s * H + w] = kk - (up ? FC_NB / 2 - 1 : FC_NB / 2);
+            return;
+        }
         PeakOut o; o.p = best; o.tie = key; o.k = kk;
         peaks[(size_t)s * H + w] = o;
     }
@@ -621,9 +632,7 @@ __device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __
 }
 
 // result of k_fine_cert for one window (see below)
-struct FineCert { double p; int t, k, a, b; int pad; };
-#define FC_NB 7
-#define FC_CHUNK 256   /* shifts per anchored segment in k_fine_cert */
+struct FineCert { double p; int t, k, a, b; int nch; int pad; };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -646,16 +655,18 @@ __global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __res
     __shared__ double sh_e[4];
     const int s = blockIdx.z, w = blockIdx.y;
     if (w >= sts[s].n_win) return;
-    if (cert) {                                 // fully certified window: nothing left to search
-        const FineCert fc = cert[(size_t)s * H + w];
-        if (fc.a == 0 && fc.b == nshift - 1) return;
+    const int nstep = nshift - 1;
+    const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
+    int nchunk = nstep_pad / FS_CHUNK;          // chunks to sweep: all of them, or the certificate's open prefix
+    if (cert) {
+        const int nch = cert[(size_t)s * H + w].nch;
+        if (nch == 0) return;                   // fully certified window: nothing left to search
+        if (nch < nchunk) nchunk = nch;
     }
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     const int tid = threadIdx.x;
-    const int nstep = nshift - 1;
-    const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
     double e = 0.0;
-    for (int t = tid; t < nstep_pad; t += 256) {
+    for (int t = tid; t < nchunk * FS_CHUNK; t += 256) {   // only the swept steps enter the recurrence and its error bound
         float2 v = make_float2(0.0f, 0.0f);
         if (t < nstep) {
             const cplx a = x[t + nfft], b = x[t];
@@ -687,7 +698,6 @@ __global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __res
 #pragma unroll
         for (int c = 0; c < PS_NCHUNK; ++c) cm[c] = (v2f){0.0f, 0.0f};
         cm[0] = p0;
-        const int nchunk = nstep_pad / FS_CHUNK;
 #pragma unroll
         for (int c = 0; c < PS_NCHUNK; ++c) {
             const int cend = (c == PS_NCHUNK - 1) ? nchunk : (c + 1 < nchunk ? c + 1 : nchunk);
@@ -715,8 +725,8 @@ __global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __res
         unsigned mk0 = 0, mk1 = 0;
 #pragma unroll
         for (int c = 0; c < PS_NCHUNK; ++c) {
-            if (sqrtf(cm[c].x) * 1.0000002f >= t0) mk0 |= 1u << c;
-            if (sqrtf(cm[c].y) * 1.0000002f >= t1) mk1 |= 1u << c;
+            if (c < nchunk && sqrtf(cm[c].x) * 1.0000002f >= t0) mk0 |= 1u << c;
+            if (c < nchunk && sqrtf(cm[c].y) * 1.0000002f >= t1) mk1 |= 1u << c;
         }
         const size_t o = ((size_t)s * H + w) * nfft;
         p32[o + k0] = bm.x;
@@ -759,9 +769,11 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (cert) {                                           // fully certified window: the certificate IS the answer
-        const FineCert fc = cert[(size_t)s * H + w];
-        if (fc.a == 0 && fc.b == nshift - 1) {
+    FineCert fc;
+    fc.p = -1.0; fc.t = 0x7fffffff; fc.k = 0x7fffffff; fc.nch = -1;
+    if (cert) {
+        fc = cert[(size_t)s * H + w];
+        if (fc.nch == 0) {                                // fully certified window: the certificate IS the answer
             if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; out[(size_t)s * H + w] = o2; }
             return;
         }
@@ -772,7 +784,10 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     __syncthreads();
     const size_t o = ((size_t)s * H + w) * nfft;
     const double E = FS_ERR_SCALE * esum[(size_t)s * H + w];
-    const double amax = sqrt((double)__uint_as_float(pmax32[(size_t)s * H + w]));
+    // the bar a bin must reach: the window's fp32 maximum over the swept chunks, or the certificate's exact
+    // maximum over its own bins (all shifts) if that is higher
+    double amax = sqrt((double)__uint_as_float(pmax32[(size_t)s * H + w]));
+    if (fc.p > 0.0 && sqrt(fc.p) > amax) amax = sqrt(fc.p);
     const int nstep = nshift - 1;
     const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
     // compact list of the candidate bins (amplitude within 2E of the window's fp32 maximum); cm_s[i] = bin
@@ -784,6 +799,7 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     const int ncand = n_cand;
     double best = -1.0;
     int bt = 0x7fffffff, bk = 0x7fffffff;
+    if (tid == 0 && fc.p > 0.0) { best = fc.p; bt = fc.t; bk = fc.k; }   // the certificate's bins compete with the rest
     // candidate bins are processed FV_BINS at a time, so the item list can never overflow whatever the input
     // (an all-zero window makes every bin and chunk a candidate); normally there are 1-3 candidates: one pass
     for (int kb = 0; kb < ncand; kb += FV_BINS) {
@@ -855,161 +871,223 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fine_cert: Parseval certificate for the fine search.  grid (H, S), block 256.
-// An FCCH window is dominated by one tone, so the global maximum over (shift, bin) is almost always in
-// the few bins S around the tone (prior = strongest bin of the start window's spectrum x0).  The kernel
-//   1. evaluates the 7 bins S = prior-3..prior+3 exactly (fp64) at all nshift shifts, with the same
-//      anchored sliding as k_fine_verify (direct-DFT anchor at each 64-shift chunk, then the recurrence),
-//      giving P* = max power, its first shift t* and bin k*;
-//   2. bounds every OTHER bin at shift t by Parseval:  P_other(t) <= R(t) = N*E(t) - sum_{k in S} P(t,k),
-//      E(t) = energy of the window starting at t (prefix sums);
-//   3. marks shift t "certified" when R(t)*(1+1e-6) < P*: no bin outside S can reach P* there.
-// Output per window: (P*, t*, k*) and the uncertified range as a prefix [0, a) and a suffix (b, nshift-1].
-// a == 0 and b == nshift-1 means the whole window is certified: (t*, k*) is the exact answer and the
-// prescreen / verify passes skip the window; otherwise they treat it in full.
-// LDS: window | energy prefix | sumS[nshift] | anchors.
+// k_fine_cert: Parseval certificate for the fine search.  grid (H, S), block 8*nchunk rounded up to whole
+// waves (nchunk = nstep/64).
+// An FCCH window is dominated by one tone, so the maximum over (shift, bin) is almost always in the few
+// bins around the tone.  With S = the FC_NB bins around the strongest bin of the start spectrum x0:
+//   1. every bin of S is evaluated exactly (fp64) at ALL shifts: lane (c, j) anchors X_k(64c) and slides
+//      through the 64 shifts of chunk c with the recurrence, tracking (max power, first shift) -> P*, t*, k*;
+//   2. every OTHER bin at shift t is bounded by Parseval:  P_other(t) <= R(t) = N*E(t) - sum_{k in S} P(t,k),
+//      E(t) = energy of the window starting at t;
+//   3. shift t is "certified" when R(t) (plus the rounding margin of the fp32 group sums) < P*.
+// The certified shifts form a range [a, b] around t*; what is left for the all-bin search is the prefix
+// [0, a) -- and, rarely, a suffix, in which case everything is searched.  Output: (P*, t*, k*), a, b and
+// nch = number of leading 64-shift chunks k_fine_prescreen still has to sweep (0: the window is settled).
+// Anchors by a two-level regrouping of the DFT sum (exact algebra, fp64): with B = gcd(64, nfft),
+//   S_k(m) = sum_{b<B} x[B*m+b] W^(k*b),   X_k(64c) = sum_{a<nfft/B} W^(k*B*a) * S_k(64c/B + a),   W = exp(-2 pi i/nfft)
+// i.e. nfft/B + (wlen/B)*B/nchunk MACs per anchor instead of nfft.
+// LDS: window | S partials (later E[nstep+1]) | twiddle tables (later the fp32 group sums).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fc_group8_sum(float v) {     // sum over the 8 lanes of a bin group, in every lane
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad
+    v += __int_as_float(t);
+    return v;
+}
 
-__global__ void __launch_bounds__(256) k_fine_cert(const StreamState* __restrict__ sts,
+__host__ __device__ inline int fc_gcd64(int n) { int b = 64; while (n % b) b >>= 1; return b; }
+__host__ inline int fc_threads(int nshift) {
+    const int n = ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64;
+    return n < 256 ? 256 : n;
+}
+__host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
+    const int nstep = nshift - 1, wlen = nstep + nfft, B = fc_gcd64(nfft);
+    size_t r1 = (size_t)FC_NB * (wlen / B) * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
+    size_t r2 = (size_t)FC_NB * (B + 2 + nfft / B) * sizeof(cplx), e2 = (size_t)(nstep + 2) * sizeof(float);
+    return (size_t)wlen * sizeof(cplx) + (r1 > e1 ? r1 : e1) + (r2 > e2 ? r2 : e2);
+}
+
+#define FC_PF 8   /* slide steps whose samples are fetched from LDS ahead of the arithmetic */
+__global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict__ sts,
                                                    const cplx* __restrict__ win, long win_stream_stride,
                                                    long win_stride, int nshift, int nfft,
-                                                   const cplx* __restrict__ tw_g, const cplx* __restrict__ x0,
+                                                   const cplx* __restrict__ tw_g, const int* __restrict__ fc_lo,
                                                    FineCert* __restrict__ cert, int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wlen = nshift - 1 + nfft;
+    const int nstep = nshift - 1, wlen = nstep + nfft;
+    const int B = fc_gcd64(nfft), nA = nfft / B, nM = wlen / B, nchunk = nstep / FS_CHUNK;
+    const int nthr = blockDim.x;                          // >= 8 * nchunk, whole waves
     cplx* xs = (cplx*)smem;                               // window
-    double* pre = (double*)(xs + wlen);                   // pre[i] = sum_{n<i} |x[n]|^2, i = 0..wlen
-    double* sumS = pre + wlen + 1;                        // sum over S of P(t,k), t = 0..nshift-1
-    cplx* anchor = (cplx*)(sumS + ((nshift + 1) & ~1));   // FC_NB * nchunk
-    __shared__ double red_p[4];
-    __shared__ int red_t[4], red_k[4];
-    __shared__ double sh_scan[4];
-    __shared__ int sh_prior, sh_a, sh_b;
+    const size_t r1 = (size_t)FC_NB * nM * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
+    cplx* Sp = xs + wlen;                                 // S partials [j][m]
+    double* Et = (double*)Sp;                             // ... later E[t], t = 0..nstep
+    unsigned char* reg2 = (unsigned char*)Sp + (r1 > e1 ? r1 : e1);
+    const int ld1 = B + 2;                                // plane stride of tw1: spreads the 8 bins over the banks
+    cplx* tw1 = (cplx*)reg2;                              // [j][b]  W^(k_j b)
+    cplx* tw2 = tw1 + FC_NB * ld1;                        // [a][j]  W^(k_j B a)
+    float* sumS = (float*)reg2;                           // ... later sum over S of P(t,k), t = 0..nstep
+    __shared__ double red_p[8];
+    __shared__ int red_t[8], red_k[8];
+    __shared__ double sh_scan[8];
+    __shared__ int sh_a, sh_b;
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    const int nstep = nshift - 1;
-    const int nchunk = (nstep + FC_CHUNK - 1) / FC_CHUNK;
-    for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
-    for (int i = tid; i < nshift; i += 256) sumS[i] = 0.0;
+    for (int i = tid; i < wlen; i += nthr) xs[i] = x[i];
     if (tid == 0) { sh_a = 0; sh_b = nstep; }
-    // ---- prior: strongest bin of the start window ----
-    {
-        const cplx* x0w = x0 + ((size_t)s * H + w) * nfft;
-        double best = -1.0;
-        int bk = 0;
-        for (int k = tid; k < nfft; k += 256) {
-            const cplx v = x0w[k];
-            const double p = v.x * v.x + v.y * v.y;
-            if (p > best) { best = p; bk = k; }
+    const int lo = fc_lo[(size_t)s * H + w];              // bins lo .. lo+FC_NB-1 (mod nfft), from k_fft_burst<1>
+    const int j = tid & (FC_NB - 1), c = tid / FC_NB;
+    const bool act = c < nchunk;                          // lanes beyond the last chunk only help with the shared phases
+    const int k = ((lo + j) % nfft + nfft) % nfft;
+    for (int i = tid; i < FC_NB * (B + nA); i += nthr) {  // twiddle tables of the FC_NB bins
+        if (i < FC_NB * B) {
+            const int jj = i / B, q = i - jj * B;
+            const int kk = ((lo + jj) % nfft + nfft) % nfft;
+            tw1[jj * ld1 + q] = tw_g[(kk * q) % nfft];
+        } else {
+            const int ii = i - FC_NB * B;
+            const int q = ii / FC_NB, jj = ii - q * FC_NB;
+            const int kk = ((lo + jj) % nfft + nfft) % nfft;
+            tw2[q * FC_NB + jj] = tw_g[(((kk * B) % nfft) * q) % nfft];
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double op = __shfl_down(best, off, 64);
-            const int ok = __shfl_down(bk, off, 64);
-            if (op > best || (op == best && ok < bk)) { best = op; bk = ok; }
-        }
-        if (lane == 0) { red_p[wave] = best; red_k[wave] = bk; }
     }
     __syncthreads();
-    if (tid == 0) {
-        double best = red_p[0];
-        int bk = red_k[0];
-        for (int i = 1; i < 4; ++i)
-            if (red_p[i] > best || (red_p[i] == best && red_k[i] < bk)) { best = red_p[i]; bk = red_k[i]; }
-        sh_prior = bk;
+    // ---- level 1: S_k(m) for all nM blocks of the window.  Lane (c, j) starts its block at sample c mod B so
+    // that the groups of a wave read different LDS banks (the 8 lanes of a group share the sample: broadcast).
+    for (int m = c; m < nM; m += nthr / FC_NB) {
+        const cplx* xb = xs + B * m;
+        const cplx* tb = tw1 + j * ld1;
+        double ar = 0.0, ai = 0.0;
+        int b = c & (B - 1);
+#pragma unroll 4
+        for (int i = 0; i < B; ++i) {
+            const cplx v = xb[b], t = tb[b];
+            ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+            ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+            b = (b + 1) & (B - 1);
+        }
+        Sp[j * nM + m] = make_double2(ar, ai);
     }
-    // ---- energy prefix sums: thread i owns elements [i*per, (i+1)*per) ----
+    __syncthreads();
+    // ---- level 2: anchor X_k(64c) ----
+    double xr = 0.0, xi = 0.0;
+    if (act) {
+        const cplx* sb = Sp + j * nM + (FS_CHUNK / B) * c;
+        const cplx* tb = tw2 + j;
+#pragma unroll 4
+        for (int a = 0; a < nA; ++a) {
+            const cplx v = sb[a], t = tb[a * FC_NB];
+            xr = fma(v.x, t.x, fma(-v.y, t.y, xr));
+            xi = fma(v.x, t.y, fma(v.y, t.x, xi));
+        }
+    }
+    __syncthreads();                                      // S and the tables are dead: E and sumS take their place
+    // ---- E(t): E(0) by a block reduction, then a block scan of g[q] = |x[q+nfft]|^2 - |x[q]|^2 ----
     {
-        const int per = (wlen + 255) / 256;
-        const int i0 = tid * per, i1 = i0 + per < wlen ? i0 + per : wlen;
+        double e0 = 0.0;
+        for (int i = tid; i < nfft; i += nthr) e0 += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
+        for (int off = 32; off > 0; off >>= 1) e0 += __shfl_down(e0, off, 64);
+        if (lane == 0) red_p[wave] = e0;
+        const int per = (nstep + nthr - 1) / nthr;
+        const int i0 = tid * per < nstep ? tid * per : nstep, i1 = i0 + per < nstep ? i0 + per : nstep;
         double loc = 0.0;
-        for (int i = i0; i < i1; ++i) loc += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
-        double inc = loc;                                  // inclusive scan across the wave
+        for (int q = i0; q < i1; ++q) {
+            const cplx a1 = xs[q + nfft], b1 = xs[q];
+            loc += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
+        }
+        double inc = loc;                                 // inclusive scan across the wave
         for (int off = 1; off < 64; off <<= 1) {
             const double o = __shfl_up(inc, off, 64);
             if (lane >= off) inc += o;
         }
         if (lane == 63) sh_scan[wave] = inc;
         __syncthreads();
-        double base = inc - loc;
-        for (int i = 0; i < wave; ++i) base += sh_scan[i];
-        double run = base;
-        for (int i = i0; i < i1; ++i) {
-            pre[i] = run;
-            run += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
+        double run = inc - loc;
+        for (int i = 0; i < wave; ++i) run += sh_scan[i];
+        for (int i = 0; i < nwave; ++i) run += red_p[i];  // + E(0)
+        for (int q = i0; q < i1; ++q) {
+            Et[q] = run;
+            const cplx a1 = xs[q + nfft], b1 = xs[q];
+            run += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
         }
-        if (i1 == wlen && i0 < wlen) pre[wlen] = run;
+        if (i1 == nstep && i0 < nstep) Et[nstep] = run;
     }
-    __syncthreads();
-    const int prior = sh_prior;
-    const int nitem = FC_NB * nchunk;
-    // ---- anchors: X_k(64c) by direct DFT, one wave per item ----
-    for (int i = wave; i < nitem; i += 4) {
-        const int j = i / nchunk, c = i - j * nchunk;
-        int k = prior - FC_NB / 2 + j;
-        k = ((k % nfft) + nfft) % nfft;
-        const int t0 = c * FC_CHUNK;
-        const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
-        const double ar = av.x, ai = av.y;
-        if (lane == 0) anchor[i] = make_double2(ar, ai);
-    }
-    __syncthreads();
-    // ---- slides: one lane per (bin, chunk); accumulate sumS, track the first maximum ----
+    // ---- slides: lane (c, j) walks chunk c of bin k; the 8 lanes of a group share the shift ----
     double best = -1.0;
-    int bt = 0x7fffffff, bk = 0x7fffffff;
-    for (int i = tid; i < nitem; i += 256) {
-        const int j = i / nchunk, c = i - j * nchunk;
-        int k = prior - FC_NB / 2 + j;
-        k = ((k % nfft) + nfft) % nfft;
-        double wi, wr;
-        sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
-        double xr = anchor[i].x, xi = anchor[i].y;
-        const int t0 = c * FC_CHUNK;
-        if (c == 0) {
+    int bt = 0x7fffffff;
+    if (act) {                                            // (uniform per 8-lane group)
+        const cplx wk = tw_g[k];                          // exp(-2 pi i k/nfft): the recurrence turns by its conjugate
+        const double wr = wk.x, wi = -wk.y;
+        const int t0 = c * FS_CHUNK;
+        if (c == 0) {                                     // the start window m = 0
             const double p = xr * xr + xi * xi;
-            atomicAdd(&sumS[0], p);
-            if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
+            best = p; bt = 0;
+            sumS[0] = fc_group8_sum((float)p);
         }
-        const int lim = nstep - t0 < FC_CHUNK ? nstep - t0 : FC_CHUNK;
-        for (int q = 0; q < lim; ++q) {
-            const cplx a1 = xs[t0 + q + nfft], b1 = xs[t0 + q];
-            const double ar = xr + (a1.x - b1.x), ai = xi + (a1.y - b1.y);
-            xr = ar * wr - ai * wi;
-            xi = ar * wi + ai * wr;
-            const double p = xr * xr + xi * xi;
-            const int m = t0 + q + 1;
-            atomicAdd(&sumS[m], p);
-            if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+        const cplx* xa = xs + t0 + nfft;
+        const cplx* xb = xs + t0;
+        for (int q0 = 0; q0 < FS_CHUNK; q0 += FC_PF) {
+            double dr[FC_PF], di[FC_PF];
+#pragma unroll
+            for (int u = 0; u < FC_PF; ++u) {             // all LDS reads of the group first: one wait, not FC_PF
+                const cplx a1 = xa[q0 + u], b1 = xb[q0 + u];
+                dr[u] = a1.x - b1.x;
+                di[u] = a1.y - b1.y;
+            }
+            float ps[FC_PF];
+#pragma unroll
+            for (int u = 0; u < FC_PF; ++u) {
+                const double ar = xr + dr[u], ai = xi + di[u];
+                xr = ar * wr - ai * wi;
+                xi = ar * wi + ai * wr;
+                const double p = xr * xr + xi * xi;
+                if (p > best) { best = p; bt = t0 + q0 + u + 1; }   // shifts ascend: strict > keeps the first maximum
+                ps[u] = fc_group8_sum((float)p);
+            }
+#pragma unroll
+            for (int u = 0; u < FC_PF; ++u) sumS[t0 + q0 + u + 1] = ps[u];
         }
     }
+    int bk = k;
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(best, off, 64);
         const int ot = __shfl_down(bt, off, 64);
         const int ok = __shfl_down(bk, off, 64);
         if (op > best || (op == best && (ot < bt || (ot == bt && ok < bk)))) { best = op; bt = ot; bk = ok; }
     }
+    __syncthreads();                                      // red_p was E(0) until here
     if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
     __syncthreads();
     best = red_p[0]; bt = red_t[0]; bk = red_k[0];
-    for (int i = 1; i < 4; ++i)
+    for (int i = 1; i < nwave; ++i)
         if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
             best = red_p[i]; bt = red_t[i]; bk = red_k[i];
         }
-    // ---- certificate per shift ----
-    for (int t = tid; t < nshift; t += 256) {
-        const double E = pre[t + nfft] - pre[t];
-        const double R = (double)nfft * E - sumS[t];
-        const bool okc = best > 0.0 && R * 1.000001 < best;
+    // ---- certificate per shift.  fp32 group sums: each of the 8 terms and 7 additions errs by <= 2^-24
+    // relative, all terms are <= N*E(t), so |sumS - exact| < 2e-6 * N*E(t); the margins below cover that and
+    // the fp64 rounding of E and P.
+    for (int t = tid; t <= nstep; t += nthr) {
+        const double NE = (double)nfft * Et[t];
+        const float ss = sumS[t];
+        const double R = NE - (double)ss + 4e-6 * NE;
+        const bool okc = best > 0.0 && ss <= 3.0e38f && R < best * (1.0 - 1e-9);   // (an overflowed fp32 sum certifies nothing)
         if (!okc) {
-            if (t <= bt) atomicMax(&sh_a, t + 1);           // uncertified prefix [0, a)
-            if (t >= bt) atomicMin(&sh_b, t - 1);           // uncertified suffix (b, nstep]
+            if (t <= bt) atomicMax(&sh_a, t + 1);         // uncertified prefix [0, a)
+            if (t >= bt) atomicMin(&sh_b, t - 1);         // uncertified suffix (b, nstep]
         }
     }
     __syncthreads();
     if (tid == 0) {
         FineCert o;
         o.p = best; o.t = bt; o.k = bk; o.a = sh_a; o.b = sh_b; o.pad = 0;
+        const int a = sh_a;
+        if (sh_b < nstep || a > bt) o.nch = nchunk;       // a suffix (or everything) is open: sweep the whole window
+        else o.nch = a == 0 ? 0 : (a == 1 ? 1 : (a - 2) / FS_CHUNK + 1);   // chunk c holds shifts 64c+1..64c+64 (+ shift 0)
         cert[(size_t)s * H + w] = o;
     }
 }
