@@ -70,6 +70,7 @@ struct gsmcal_ctx {
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
+    int lane_min = 32;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, the prescreen sweeps every window in full
     bool capturing = false;
     // shared workspace
@@ -589,7 +590,7 @@ int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
 // Split d units over the lanes: returns the number of lanes used and fills lo/n per lane.
 int plan_lanes(gsmcal_ctx* c, int d) {
     int nl = c->n_lanes_cfg;
-    if (nl > d / 64) nl = d / 64;        // at least 64 streams per lane: below that splitting only adds launches
+    if (nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl < 1) nl = 1;
     for (int i = 0; i < nl; ++i) {
         c->lanes[i].lo = (int)(((long)i * d) / nl);
@@ -713,6 +714,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     c->cur = &c->lanes[0];
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
+    const char* lm = getenv("GSMCAL_LANE_MIN");
+    if (lm && atoi(lm) >= 1) c->lane_min = atoi(lm);
     const char* ce = getenv("GSMCAL_CERT");
     if (ce) c->certify = atoi(ce) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");

@@ -907,7 +907,7 @@ __host__ inline int fc_threads(int nshift) {
 __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
     const int nstep = nshift - 1, wlen = nstep + nfft, B = fc_gcd64(nfft);
     size_t r1 = (size_t)FC_NB * (wlen / B) * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
-    size_t r2 = (size_t)FC_NB * (B + 2 + nfft / B) * sizeof(cplx), e2 = (size_t)(nstep + 2) * sizeof(float);
+    size_t r2 = (size_t)FC_NB * (B + 2 + nfft / B) * sizeof(cplx), e2 = (size_t)2 * (nstep + 2) * sizeof(float);
     return (size_t)wlen * sizeof(cplx) + (r1 > e1 ? r1 : e1) + (r2 > e2 ? r2 : e2);
 }
 
@@ -930,9 +930,10 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     cplx* tw1 = (cplx*)reg2;                              // [j][b]  W^(k_j b)
     cplx* tw2 = tw1 + FC_NB * ld1;                        // [a][j]  W^(k_j B a)
     float* sumS = (float*)reg2;                           // ... later sum over S of P(t,k), t = 0..nstep
+    float* Cs = sumS + (nstep + 2);                       // ... and C(t) = sum_{q<t} |d_q|, the slack of the recurrence
     __shared__ double red_p[8];
     __shared__ int red_t[8], red_k[8];
-    __shared__ double sh_scan[8];
+    __shared__ double sh_scan[8], sh_scan2[8];
     __shared__ int sh_a, sh_b;
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
@@ -995,27 +996,32 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (lane == 0) red_p[wave] = e0;
         const int per = (nstep + nthr - 1) / nthr;
         const int i0 = tid * per < nstep ? tid * per : nstep, i1 = i0 + per < nstep ? i0 + per : nstep;
-        double loc = 0.0;
+        double loc = 0.0, locd = 0.0;
         for (int q = i0; q < i1; ++q) {
             const cplx a1 = xs[q + nfft], b1 = xs[q];
             loc += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
+            const double dr = a1.x - b1.x, di = a1.y - b1.y;
+            locd += sqrt(dr * dr + di * di);
         }
-        double inc = loc;                                 // inclusive scan across the wave
+        double inc = loc, incd = locd;                    // inclusive scans across the wave
         for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
+            const double o = __shfl_up(inc, off, 64), od = __shfl_up(incd, off, 64);
+            if (lane >= off) { inc += o; incd += od; }
         }
-        if (lane == 63) sh_scan[wave] = inc;
+        if (lane == 63) { sh_scan[wave] = inc; sh_scan2[wave] = incd; }
         __syncthreads();
-        double run = inc - loc;
-        for (int i = 0; i < wave; ++i) run += sh_scan[i];
+        double run = inc - loc, rund = incd - locd;
+        for (int i = 0; i < wave; ++i) { run += sh_scan[i]; rund += sh_scan2[i]; }
         for (int i = 0; i < nwave; ++i) run += red_p[i];  // + E(0)
         for (int q = i0; q < i1; ++q) {
             Et[q] = run;
+            Cs[q] = (float)rund;
             const cplx a1 = xs[q + nfft], b1 = xs[q];
             run += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
+            const double dr = a1.x - b1.x, di = a1.y - b1.y;
+            rund += sqrt(dr * dr + di * di);
         }
-        if (i1 == nstep && i0 < nstep) Et[nstep] = run;
+        if (i1 == nstep && i0 < nstep) { Et[nstep] = run; Cs[nstep] = (float)rund; }
     }
     // ---- slides: lane (c, j) walks chunk c of bin k; the 8 lanes of a group share the shift ----
     double best = -1.0;
@@ -1068,17 +1074,61 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
             best = red_p[i]; bt = red_t[i]; bk = red_k[i];
         }
-    // ---- certificate per shift.  fp32 group sums: each of the 8 terms and 7 additions errs by <= 2^-24
-    // relative, all terms are <= N*E(t), so |sumS - exact| < 2e-6 * N*E(t); the margins below cover that and
-    // the fp64 rounding of E and P.
-    for (int t = tid; t <= nstep; t += nthr) {
-        const double NE = (double)nfft * Et[t];
-        const float ss = sumS[t];
-        const double R = NE - (double)ss + 4e-6 * NE;
-        const bool okc = best > 0.0 && ss <= 3.0e38f && R < best * (1.0 - 1e-9);   // (an overflowed fp32 sum certifies nothing)
-        if (!okc) {
-            if (t <= bt) atomicMax(&sh_a, t + 1);         // uncertified prefix [0, a)
-            if (t >= bt) atomicMin(&sh_b, t - 1);         // uncertified suffix (b, nstep]
+    // ---- certificate per shift.  Two bounds on every bin outside S:
+    //   Parseval at the shift itself:            |X_k(t)| <= s(t) = sqrt(R(t))
+    //   the recurrence from any other shift t':  |X_k(t)| <= s(t') + |C(t) - C(t')|   (each step adds at most |d_q|)
+    // so U(t) = min( C(t) + min_{t'<=t}(s(t') - C(t')),  -C(t) + min_{t'>=t}(s(t') + C(t')) ) and shift t is certified
+    // when U(t) < sqrt(P*).  fp32 group sums: each of the 8 terms and 7 additions errs by <= 2^-24 relative, all
+    // terms are <= N*E(t), so |sumS - exact| < 2e-6 * N*E(t); the margins cover that, the fp32 storage of s and C
+    // and the fp64 rounding of E and P.
+    {
+        const double INF = __longlong_as_double(0x7ff0000000000000LL);
+        const double sb = best > 0.0 ? sqrt(best) * (1.0 - 1e-9) : -1.0;
+        const int per = (nstep + nthr) / nthr;            // >= ceil((nstep+1)/nthr)
+        const int u0 = tid * per < nstep + 1 ? tid * per : nstep + 1, u1 = u0 + per < nstep + 1 ? u0 + per : nstep + 1;
+        double mf = INF, mb = INF;
+        for (int t = u0; t < u1; ++t) {
+            const double NE = (double)nfft * Et[t];
+            const float ss = sumS[t];
+            const double R = NE - (double)ss + 4e-6 * NE;
+            double sv = ss <= 3.0e38f ? sqrt(R > 0.0 ? R : 0.0) * (1.0 + 1e-6) : INF;   // (an overflowed fp32 sum bounds nothing)
+            if (!(sv >= 0.0)) sv = INF;                   // NaN input
+            const float sf = (float)sv;
+            sumS[t] = sf;                                 // own range only: s(t) replaces the group sum
+            const double cv = (double)Cs[t];
+            mf = fmin(mf, (double)sf - cv);
+            mb = fmin(mb, (double)sf + cv);
+        }
+        double pf = mf, pb = mb;                          // inclusive prefix-min / suffix-min across the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(pf, off, 64), ob = __shfl_down(pb, off, 64);
+            if (lane >= off) pf = fmin(pf, o);
+            if (lane + off < 64) pb = fmin(pb, ob);
+        }
+        __syncthreads();                                  // sh_scan / sh_scan2 are free again
+        if (lane == 63) sh_scan[wave] = pf;
+        if (lane == 0) sh_scan2[wave] = pb;
+        double ef = __shfl_up(pf, 1, 64), eb = __shfl_down(pb, 1, 64);   // exclusive parts inside the wave
+        if (lane == 0) ef = INF;
+        if (lane == 63) eb = INF;
+        __syncthreads();
+        for (int i = 0; i < wave; ++i) ef = fmin(ef, sh_scan[i]);
+        for (int i = wave + 1; i < nwave; ++i) eb = fmin(eb, sh_scan2[i]);
+        const double ctot = (double)Cs[nstep] * 1e-6;     // covers the fp32 rounding of the C(t) differences
+        unsigned okm = 0;                                 // per <= 32 for every supported geometry
+        for (int t = u0; t < u1; ++t) {
+            const double cv = (double)Cs[t];
+            ef = fmin(ef, (double)sumS[t] - cv);
+            if (cv + ef + ctot < sb) okm |= 1u << (t - u0);
+        }
+        for (int t = u1 - 1; t >= u0; --t) {
+            const double cv = (double)Cs[t];
+            eb = fmin(eb, (double)sumS[t] + cv);
+            const bool okc = ((okm >> (t - u0)) & 1u) || (eb - cv + ctot < sb);
+            if (!okc) {
+                if (t <= bt) atomicMax(&sh_a, t + 1);     // uncertified prefix [0, a)
+                if (t >= bt) atomicMin(&sh_b, t - 1);     // uncertified suffix (b, nstep]
+            }
         }
     }
     __syncthreads();

@@ -35,7 +35,7 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 __device__ unsigned long long* g_bt_dbg = nullptr;   // development aid: per-phase timestamps of k_burst_tone
 #define BT_STAMP(i) do { if (g_bt_dbg && tid == 0) g_bt_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 template <int GATE>
-__global__ void __launch_bounds__(BT_THREADS) k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft,
+__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft,
                                                            const cplx* __restrict__ tw_g, int ov, int prior_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red_p[BT_THREADS / 64];
