@@ -42,7 +42,7 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, p32, pmax32, esum, cmask, cert, fclo, partial;
+    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
@@ -70,6 +70,7 @@ struct gsmcal_ctx {
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
+    int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 32;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, the prescreen sweeps every window in full
     bool capturing = false;
@@ -280,58 +281,57 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
     RET_IF(ensure(c, c->cur->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
-    RET_IF(ensure(c, c->cur->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
-    RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
     RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->cur->win.p;
     PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
-    // Parseval certificate (k_fine_cert): settles most windows outright and leaves the all-bin sweep a short prefix
-    const int fc_thr = fc_threads(g.fine_nshift);
-    const size_t clds = (fc_lds_bytes(g.fine_nshift, g.nfft) + 15) & ~(size_t)15;
-    const bool use_cert = c->prescreen && c->certify && fc_thr <= 512 && clds <= 159 * 1024 &&
-                          (g.fine_nshift - 1) % FS_CHUNK == 0 && g.nfft >= 2 * FC_NB;
-    if (use_cert) RET_IF(ensure(c, c->cur->fclo, (size_t)S * H * sizeof(int)));
-    LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
-           wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H,
-           c->prescreen ? (unsigned int*)c->cur->pmax32.p : (unsigned int*)nullptr,
-           use_cert ? (int*)c->cur->fclo.p : (int*)nullptr);
     StepArgs sa_fine = sa;
     if (c->prescreen) {
-        // two-pass fine search: packed-fp32 prescreen of every (bin, shift), exact fp64 on the candidates only
-        RET_IF(ensure(c, c->cur->p32, (size_t)S * H * g.nfft * sizeof(float)));
-        RET_IF(ensure(c, c->cur->cmask, (size_t)S * H * g.nfft * sizeof(unsigned short)));
-        RET_IF(ensure(c, c->cur->pmax32, (size_t)S * H * sizeof(unsigned int)));
-        RET_IF(ensure(c, c->cur->esum, (size_t)S * H * sizeof(double)));
+        // certificate (exact, tone bins) -> packed-fp32 sweep of the chunks it left open -> exact fp64 on what survives
+        const int nchunk = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK;
+        if (nchunk > 255) return GSMCAL_E_UNSUPPORTED;     // (items carry the chunk in 8 bits; ov <= 127)
+        if ((long)S * H >= (1L << 23)) return GSMCAL_E_UNSUPPORTED;
+        RET_IF(ensure(c, c->cur->chunkrec, (size_t)S * H * nchunk * sizeof(ChunkRec)));
+        // open-chunk work list: [0] = count (cleared by k_fine_verify after use), [4..] = items
+        const size_t need_list = ((size_t)S * H * nchunk + 4) * sizeof(int);
+        if (c->cur->openlist.cap < need_list) {
+            RET_IF(ensure(c, c->cur->openlist, need_list));
+            HIPCHK(c, hipMemsetAsync(c->cur->openlist.p, 0, 16, c->cur->stream));
+        }
+        int* n_open = (int*)c->cur->openlist.p;
+        int* open_items = n_open + 4;
         const FineCert* certp = nullptr;
-        if (use_cert) {
+        const int fc_thr = fc_threads(g.fine_nshift);
+        const size_t clds = (fc_lds_bytes(g.fine_nshift, g.nfft) + 15) & ~(size_t)15;
+        if (c->certify && fc_thr <= 512 && clds <= 159 * 1024 && (g.fine_nshift - 1) % FS_CHUNK == 0 &&
+            g.nfft % 148 == 0 && g.nfft >= 2 * FC_NB) {
             RET_IF(ensure(c, c->cur->cert, (size_t)S * H * sizeof(FineCert)));
             LAUNCH(c, k_fine_cert, dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const int*)c->cur->fclo.p, (FineCert*)c->cur->cert.p, H);
+                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open);
             certp = (const FineCert*)c->cur->cert.p;
+        } else {
+            LAUNCH(c, k_fine_openall, dim3(H, S), dim3(64), 0, (const StreamState*)st, nchunk, H, open_items, n_open);
         }
-        const int nbp = (g.nfft / 2 + 255) / 256;          // two bins per lane
-        const int nstep_pad = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
-        LAUNCH(c, k_fine_prescreen, dim3(nbp, H, S), dim3(256), (size_t)nstep_pad * sizeof(float2),
-               (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
-               (float*)c->cur->p32.p, (unsigned short*)c->cur->cmask.p, (unsigned int*)c->cur->pmax32.p,
-               (double*)c->cur->esum.p, H, certp);
-        if ((g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK > 2 * PS_NCHUNK) return GSMCAL_E_UNSUPPORTED;
-        const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) +
-                             (size_t)g.nfft * sizeof(unsigned short) + 15) & ~(size_t)15;
+        long nblk = (long)S * H * nchunk;                  // persistent blocks: three fit a CU
+        if (nblk > 3 * c->n_cu) nblk = 3 * c->n_cu;
+        LAUNCH(c, k_fine_chunk, dim3((unsigned)nblk), dim3(FK_THREADS), fk_lds_bytes(g.nfft),
+               (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->tw.p, certp,
+               (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
+        const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) + 15) & ~(size_t)15;
         LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-               g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const float*)c->cur->p32.p,
-               (const unsigned short*)c->cur->cmask.p, (const unsigned int*)c->cur->pmax32.p,
-               (const double*)c->cur->esum.p, peaks, H, certp);
+               g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const ChunkRec*)c->cur->chunkrec.p, peaks, H, certp, n_open);
         sa_fine.NB = 1;
     } else {
+        RET_IF(ensure(c, c->cur->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
+        LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
+               wstride, g.nfft, (const cplx*)c->tw.p, (PeakOut*)nullptr, (cplx*)c->cur->x0.p, H);
         LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
                (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
                peaks, H, g.NB);
     }
-    if (c->prescreen && getenv("GSMCAL_DBG_CERT") && c->cur->cert.p) {   // histogram of the certificate's open chunks
+    if (c->prescreen && c->certify && getenv("GSMCAL_DBG_CERT") && c->cur->cert.p) {   // histogram of the certificate's open chunks
         (void)hipStreamSynchronize(c->cur->stream);
         std::vector<FineCert> hc((size_t)S * H);
         std::vector<StreamState> hs(S);
@@ -698,6 +698,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_cert, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fine_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -714,6 +715,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     c->cur = &c->lanes[0];
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     const char* lm = getenv("GSMCAL_LANE_MIN");
     if (lm && atoi(lm) >= 1) c->lane_min = atoi(lm);
     const char* ce = getenv("GSMCAL_CERT");
@@ -751,7 +753,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.p32, &L.pmax32, &L.esum, &L.cmask, &L.cert, &L.fclo, &L.partial};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);

@@ -507,8 +507,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
                                                            const cplx* __restrict__ win, long win_stream_stride,
                                                            long win_stride, int nfft,
                                                            const cplx* __restrict__ tw_g, PeakOut* __restrict__ peaks,
-                                                           cplx* __restrict__ x0, int H,
-                                                           unsigned int* __restrict__ pmax32, int* __restrict__ fc_lo) {
+                                                           cplx* __restrict__ x0, int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N2 = nfft / 37;
     const int ldb = N2 + 1;                     // padded row: conflict-free column reads in step 2
@@ -521,7 +520,6 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x;
-    if (MODE == 1 && pmax32 && tid == 0) pmax32[(size_t)s * H + w] = 0u;   // reset for k_fine_prescreen's atomicMax
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < nfft; i += FFT_THREADS) xs[i] = x[i];
     fft37_tables(w37, wN2, N2, tid);
@@ -535,15 +533,13 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
         const double ar = X.x, ai = X.y;
         if (MODE == 1) {
             x0[((size_t)s * H + w) * nfft + k] = make_double2(ar, ai);
-            const double p = ar * ar + ai * ai;
-            if (p > best) { best = p; key = k; kk = k; }     // (ascending k per thread: first maximum)
         } else {
             const double p = ar * ar + ai * ai;
             const int sk = (k + nfft / 2) % nfft;            // position after fftshift
             if (p > best || (p == best && sk < key)) { best = p; key = sk; kk = k; }
         }
     }
-    if (MODE == 1 && !fc_lo) return;
+    if (MODE == 1) return;
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(best, off, 64);
         const int ok = __shfl_down(key, off, 64);
@@ -556,14 +552,6 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
     if (tid == 0) {
         for (int i = 1; i < FFT_THREADS / 64; ++i)
             if (red_p[i] > best || (red_p[i] == best && red_t[i] < key)) { best = red_p[i]; key = red_t[i]; kk = red_k[i]; }
-        if (MODE == 1) {
-            // k_fine_cert's bins: the FC_NB around the strongest bin of the start window, leaning to its stronger side
-            const cplx u = fft37_step2_bin(B, wN2, N2, ldb, (kk + 1) % nfft);
-            const cplx d = fft37_step2_bin(B, wN2, N2, ldb, (kk + nfft - 1) % nfft);
-            const bool up = u.x * u.x + u.y * u.y > d.x * d.x + d.y * d.y;
-            fc_lo[(size_t)s * H + w] = kk - (up ? FC_NB / 2 - 1 : FC_NB / 2);
-            return;
-        }
         PeakOut o; o.p = best; o.tie = key; o.k = kk;
         peaks[(size_t)s * H + w] = o;
     }
@@ -571,31 +559,28 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 
 // ------------------------------------------------------------------------------------------------
 // Fine search, FCCH_fine_correction.m:48-52: argmax over the nshift = 128*ov+1 window starts of
-// max_k |FFT_nfft(window)|^2, as an exact sliding DFT in fp64: one bin per lane,
-//   X_k(m+1) = (X_k(m) + x[m+nfft] - x[m]) * exp(+2*pi*i*k/nfft),   X_k(0) from k_fft_burst<1>.
-//
-// Two passes over the (bin, shift) plane:
-//  1. k_fine_prescreen (fp32): the same recurrence in single precision for EVERY bin, keeping only each
-//     bin's maximum power over the shifts and the window's overall maximum.  fp32 issues at twice the
-//     fp64 rate, and this pass has no argmax bookkeeping.
-//  2. k_fine_search (fp64): the exact recurrence, but only for CANDIDATE bins -- those whose fp32
-//     maximum amplitude lies within 2E of the window's fp32 maximum, where E bounds the fp32 error:
-//        |X32 - X| <= 1024 steps * ~5 ulp32 * (sum|x0 terms| + sum|d|) < 2^-10 * (sum|x[0..nfft)| + sum|d|)
-//     (triangle inequality on the unrolled recurrence; |re|+|im| is used as an upper bound of |z|).
-//     The bin holding the true fp64 maximum always passes this test, every passing bin is evaluated
-//     with the unchanged fp64 arithmetic, so the result equals that of running fp64 on all bins.
-//     Typically 1-3 of the 1184 bins are candidates.
-// The fp64 hot loop carries only the recurrence (6 ops), |X|^2 (2) and ONE v_max_f64: steps are
-// processed in chunks of FS_CHUNK; per chunk the lane keeps the chunk maximum, and only when a chunk
-// beats the running best (strictly) does it remember the chunk index and the state the chunk started
-// from.  After the loop the block reduces to its winning lane ("larger power, then smaller start" =
-// MATLAB's first-max rule for max(max(|fft|^2,[],1))), and that lane alone replays its winning chunk
-// -- the same operations on the same operands, hence bit-identical powers -- to find the first step
-// that attains the maximum.
-// grid (NB, H, S), block 256; bin k = blockIdx.x*256 + tid.  LDS: nshift-1 differences.
+// max_k |FFT_nfft(window)|^2 (first maximum), evaluated as a sliding DFT
+//   X_k(m+1) = (X_k(m) + x[m+nfft] - x[m]) * exp(+2*pi*i*k/nfft)
+// in three kernels over 64-shift chunks (chunk c = shifts 64c+1 .. 64c+64; shift 0 rides with chunk 0):
+//  1. k_fine_cert  (fp64, exact): the FC_NB bins around the tone at ALL shifts -> (P*, t*, k*), plus a
+//     certificate (Parseval + recurrence slack) that no other bin can reach P* on the shifts [a, b]; what is
+//     left open is a short prefix of chunks (nch), usually none.
+//  2. k_fine_chunk (packed fp32): one block per OPEN (window, chunk): all-bin spectrum at the chunk's first
+//     shift by the 37 x N2 FFT (fp64), then 64 steps of the recurrence in single precision for every bin,
+//     two bins per lane (v_pk_*_f32).  It keeps each bin's maximum power over the chunk and hands on only the
+//     bins that could still matter:  sqrt(p32) + E_c >= max(sqrt(P*), chunk maximum - E_c), where E_c bounds
+//     the fp32 error of the chunk:  |X32 - X| <= (2^-24 + 64 steps * 16 ulp32) * (sum|x window| + sum|d|)
+//     < 2^-13 * (...)  (triangle inequality on the unrolled recurrence; |re|+|im| bounds |z|).
+//  3. k_fine_verify (fp64, exact): every surviving (bin, chunk) whose fp32 amplitude + E_c reaches
+//     L = max(sqrt(P*), max_c(chunk maximum - E_c)) is re-evaluated with an fp64 anchor and the fp64
+//     recurrence; the first maximum of those and (P*, t*, k*) is the result.  The pair holding the true fp64
+//     maximum always passes (its fp32 amplitude is within E_c of the truth, and L never exceeds the truth),
+//     so the result equals that of running fp64 on every (bin, shift).
+// GSMCAL_CERT=0 opens every chunk of every window; GSMCAL_PRESCREEN=0 runs k_fine_search, the plain all-bin
+// fp64 sweep, as the cross-check of the whole scheme.
 // ------------------------------------------------------------------------------------------------
 #define FS_CHUNK 64
-#define FS_ERR_SCALE 0.0009765625   /* 2^-10 */
+#define FS_ERR_SCALE_CHUNK 0.0001220703125   /* 2^-13 */
 
 // X_k at one shift by a direct fp64 DFT over the nfft samples xw[0..nfft), executed by one wave: lane l sums
 // the terms n = l, l+64, ... (fixed order), then a shuffle tree adds the 64 partials.  The 19 table loads of a
@@ -636,141 +621,185 @@ struct FineCert { double p; int t, k, a, b; int nch; int pad; };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// grid (NBP, H, S), block 256; lane g handles bins 2g and 2g+1 (packed fp32: v_pk_add/mul/fma_f32).
-// Outputs per bin: the fp32 maximum power over all shifts (p32) and a 16-bit mask of the FS_CHUNK-step
-// chunks whose fp32 maximum amplitude is within 2E of the bin's own maximum (chunk c covers shifts
-// 64c+1 .. 64c+64; bit 15 also stands for every later chunk when nshift > 1025).  Per window: the
-// overall fp32 maximum (pmax32, atomicMax on the float bits) and the error-bound sum esum.
-#define PS_NCHUNK 16
-__global__ void __launch_bounds__(256) k_fine_prescreen(const StreamState* __restrict__ sts,
-                                                        const cplx* __restrict__ win, long win_stream_stride,
-                                                        long win_stride, int nshift, int nfft,
-                                                        const cplx* __restrict__ x0, float* __restrict__ p32,
-                                                        unsigned short* __restrict__ cmask,
-                                                        unsigned int* __restrict__ pmax32,
-                                                        double* __restrict__ esum, int H,
-                                                        const FineCert* __restrict__ cert) {
+// what k_fine_chunk hands to k_fine_verify for one (window, chunk): 256 bytes
+#define FK_CAP 30
+struct ChunkCand { int k; float p; };
+struct ChunkRec {
+    float amax;                 // largest fp32 power of the chunk (any bin)
+    int count;                  // candidates listed; -1: more than FK_CAP (verify then tries every bin of the chunk)
+    double E;                   // fp32 amplitude error bound of the chunk
+    ChunkCand cand[FK_CAP];
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_fine_chunk: grid (nchunk, H, S), block FK_THREADS.  Blocks of chunks the certificate closed exit at once.
+// LDS: xs[nfft+64] | B[37][N2+1] | w37 (40) | wN2 | d[64] (float2).
+// ------------------------------------------------------------------------------------------------
+#define FK_THREADS 640
+__host__ inline size_t fk_lds_bytes(int nfft) {
+    const int N2 = nfft / 37;
+    return ((size_t)nfft + FS_CHUNK + (size_t)37 * (N2 + 1) + 40 + N2) * sizeof(cplx) + FS_CHUNK * sizeof(float2);
+}
+__global__ void __launch_bounds__(FK_THREADS) k_fine_chunk(const cplx* __restrict__ win, long win_stream_stride,
+                                                          long win_stride, int nshift, int nfft,
+                                                          const cplx* __restrict__ tw_g, const FineCert* __restrict__ cert,
+                                                          ChunkRec* __restrict__ rec, int H,
+                                                          const int* __restrict__ items, const int* __restrict__ n_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* d = (float2*)smem;                  // nstep_pad differences, single precision (zero padded)
-    __shared__ double sh_e[4];
-    const int s = blockIdx.z, w = blockIdx.y;
-    if (w >= sts[s].n_win) return;
-    const int nstep = nshift - 1;
-    const int nstep_pad = (nstep + FS_CHUNK - 1) / FS_CHUNK * FS_CHUNK;
-    int nchunk = nstep_pad / FS_CHUNK;          // chunks to sweep: all of them, or the certificate's open prefix
-    if (cert) {
-        const int nch = cert[(size_t)s * H + w].nch;
-        if (nch == 0) return;                   // fully certified window: nothing left to search
-        if (nch < nchunk) nchunk = nch;
-    }
-    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+    const int N2 = nfft / 37, ldb = N2 + 1;
+    cplx* xs = (cplx*)smem;                     // nfft + FS_CHUNK samples from the chunk's first shift
+    cplx* B = xs + nfft + FS_CHUNK;
+    cplx* w37 = B + 37 * ldb;
+    cplx* wN2 = w37 + 40;
+    float2* d = (float2*)(wN2 + N2);
+    __shared__ double sh_e[FK_THREADS / 64];
+    __shared__ float sh_m[FK_THREADS / 64];
+    __shared__ int sh_cnt;
     const int tid = threadIdx.x;
-    double e = 0.0;
-    for (int t = tid; t < nchunk * FS_CHUNK; t += 256) {   // only the swept steps enter the recurrence and its error bound
-        float2 v = make_float2(0.0f, 0.0f);
-        if (t < nstep) {
-            const cplx a = x[t + nfft], b = x[t];
-            const double dr = a.x - b.x, di = a.y - b.y;
+    const int nstep = nshift - 1;
+    const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
+    const int total = *n_items;
+    fft37_tables(w37, wN2, N2, tid);
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {   // open (window, chunk) items, block-uniform
+    const int item = items[it];
+    const int c = item & 0xFF, widx = item >> 8, s = widx / H, w = widx - s * H;
+    const double pstar = cert && cert[widx].p > 0.0 ? cert[widx].p : 0.0;
+    const int t0 = c * FS_CHUNK;
+    const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
+    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride + t0;
+    __syncthreads();                            // (LDS of the previous item is free)
+    for (int i = tid; i < nfft + lim; i += FK_THREADS) xs[i] = x[i];
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    double e = 0.0;                             // error-bound sum: |re|+|im| of the anchor window and of the steps
+    for (int i = tid; i < nfft; i += FK_THREADS) e += fabs(xs[i].x) + fabs(xs[i].y);
+    if (tid < FS_CHUNK) {
+        float2 v = make_float2(0.0f, 0.0f);     // (zero-padded steps only rotate X: |X| unchanged)
+        if (tid < lim) {
+            const cplx a1 = xs[tid + nfft], b1 = xs[tid];
+            const double dr = a1.x - b1.x, di = a1.y - b1.y;
             v = make_float2((float)dr, (float)di);
             e += fabs(dr) + fabs(di);
         }
-        d[t] = v;
+        d[tid] = v;
     }
-    for (int t = tid; t < nfft; t += 256) e += fabs(x[t].x) + fabs(x[t].y);
     for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
     if ((tid & 63) == 0) sh_e[tid >> 6] = e;
+    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, FK_THREADS);
     __syncthreads();
-    const double es = sh_e[0] + sh_e[1] + sh_e[2] + sh_e[3];     // same value in every block of the window
-    if (blockIdx.x == 0 && tid == 0) esum[(size_t)s * H + w] = es;
-    const float twoE = (float)(2.0 * FS_ERR_SCALE * es * 1.0000002);   // rounded up
-    const int k0 = 2 * (blockIdx.x * 256 + tid);
+    double es = 0.0;
+    for (int i = 0; i < FK_THREADS / 64; ++i) es += sh_e[i];
+    const double E = FS_ERR_SCALE_CHUNK * es;
+    // ---- sweep: lane g owns bins 2g, 2g+1 (one pass whenever nfft <= 2*FK_THREADS) ----
+    const int npair = (nfft + 1) >> 1;
+    const double sp = sqrt(pstar);
+    ChunkRec* r = rec + ((size_t)s * H + w) * nchunk + c;
     float m = 0.0f;
-    if (k0 < nfft) {
-        const int k1 = k0 + 1 < nfft ? k0 + 1 : k0;
-        double wi0, wr0, wi1, wr1;
-        sincospi(2.0 * (double)k0 / (double)nfft, &wi0, &wr0);
-        sincospi(2.0 * (double)k1 / (double)nfft, &wi1, &wr1);
-        const v2f wr = {(float)wr0, (float)wr1}, wi = {(float)wi0, (float)wi1};
-        const cplx* x0w = x0 + ((size_t)s * H + w) * nfft;
-        v2f xr = {(float)x0w[k0].x, (float)x0w[k1].x}, xi = {(float)x0w[k0].y, (float)x0w[k1].y};
-        const v2f p0 = xr * xr + xi * xi;       // window start m = 0 (belongs to chunk 0 for the mask)
-        v2f cm[PS_NCHUNK];
-#pragma unroll
-        for (int c = 0; c < PS_NCHUNK; ++c) cm[c] = (v2f){0.0f, 0.0f};
-        cm[0] = p0;
-#pragma unroll
-        for (int c = 0; c < PS_NCHUNK; ++c) {
-            const int cend = (c == PS_NCHUNK - 1) ? nchunk : (c + 1 < nchunk ? c + 1 : nchunk);
-            for (int cc = c; cc < cend; ++cc) {          // one chunk per mask bit (the last bit takes any excess)
-                const float2* dc = d + cc * FS_CHUNK;
-                v2f best = cm[c];
+    for (int g0 = 0; g0 < npair; g0 += FK_THREADS) {         // block-uniform trip count
+        const int g = g0 + tid;
+        const bool act = g < npair;
+        const int k0 = 2 * g, k1 = k0 + 1 < nfft ? k0 + 1 : k0;
+        v2f best = {0.0f, 0.0f};
+        if (act) {
+            const cplx X0 = fft37_step2_bin(B, wN2, N2, ldb, k0), X1 = fft37_step2_bin(B, wN2, N2, ldb, k1);
+            const cplx t0w = tw_g[k0], t1w = tw_g[k1];       // exp(-2 pi i k/nfft): the recurrence turns by the conjugate
+            const v2f wr = {(float)t0w.x, (float)t1w.x}, wi = {(float)-t0w.y, (float)-t1w.y};
+            v2f xr = {(float)X0.x, (float)X1.x}, xi = {(float)X0.y, (float)X1.y};
+            if (c == 0) best = xr * xr + xi * xi;            // the start window m = 0 rides with chunk 0
 #pragma unroll 8
-                for (int t = 0; t < FS_CHUNK; ++t) {     // zero-padded steps only rotate X: |X| unchanged
-                    const float2 dv = dc[t];
-                    const v2f dr = {dv.x, dv.x}, di = {dv.y, dv.y};
-                    const v2f ar = xr + dr, ai = xi + di;
-                    xr = ar * wr - ai * wi;
-                    xi = ar * wi + ai * wr;
-                    const v2f p = xr * xr + xi * xi;
-                    best.x = fmaxf(best.x, p.x);
-                    best.y = fmaxf(best.y, p.y);
-                }
-                cm[c] = best;
+            for (int t = 0; t < FS_CHUNK; ++t) {
+                const float2 dv = d[t];
+                const v2f dr = {dv.x, dv.x}, di = {dv.y, dv.y};
+                const v2f ar = xr + dr, ai = xi + di;
+                xr = ar * wr - ai * wi;
+                xi = ar * wi + ai * wr;
+                const v2f p = xr * xr + xi * xi;
+                best.x = fmaxf(best.x, p.x);
+                best.y = fmaxf(best.y, p.y);
             }
+            if (k1 == k0) best.y = 0.0f;
+            m = fmaxf(m, fmaxf(best.x, best.y));
         }
-        v2f bm = cm[0];
-#pragma unroll
-        for (int c = 1; c < PS_NCHUNK; ++c) { bm.x = fmaxf(bm.x, cm[c].x); bm.y = fmaxf(bm.y, cm[c].y); }
-        const float t0 = sqrtf(bm.x) - twoE, t1 = sqrtf(bm.y) - twoE;
-        unsigned mk0 = 0, mk1 = 0;
-#pragma unroll
-        for (int c = 0; c < PS_NCHUNK; ++c) {
-            if (c < nchunk && sqrtf(cm[c].x) * 1.0000002f >= t0) mk0 |= 1u << c;
-            if (c < nchunk && sqrtf(cm[c].y) * 1.0000002f >= t1) mk1 |= 1u << c;
+        // the largest power seen by the block so far: the listing test below needs it (a later pass can only raise
+        // it, so testing against the running value is a weaker, still necessary, condition)
+        float mm = m;
+        for (int off = 32; off > 0; off >>= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) sh_m[tid >> 6] = mm;
+        __syncthreads();
+        float bm = sh_m[0];
+        for (int i = 1; i < FK_THREADS / 64; ++i) bm = fmaxf(bm, sh_m[i]);
+        // a pair can only matter if sqrt(p) + E >= max(sqrt(P*), sqrt(bm) - E)
+        double thr = sqrt((double)bm) - E;
+        if (sp > thr) thr = sp;
+        thr = (thr - E) * (1.0 - 1e-6);
+        if (act && sqrt((double)best.x) >= thr) {
+            const int i = atomicAdd(&sh_cnt, 1);
+            if (i < FK_CAP) { r->cand[i].k = k0; r->cand[i].p = best.x; }
         }
-        const size_t o = ((size_t)s * H + w) * nfft;
-        p32[o + k0] = bm.x;
-        cmask[o + k0] = (unsigned short)mk0;
-        if (k0 + 1 < nfft) { p32[o + k0 + 1] = bm.y; cmask[o + k0 + 1] = (unsigned short)mk1; }
-        m = fmaxf(bm.x, k0 + 1 < nfft ? bm.y : 0.0f);
+        if (act && k1 != k0 && sqrt((double)best.y) >= thr) {
+            const int i = atomicAdd(&sh_cnt, 1);
+            if (i < FK_CAP) { r->cand[i].k = k1; r->cand[i].p = best.y; }
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-    if ((tid & 63) == 0) atomicMax(&pmax32[(size_t)s * H + w], __float_as_uint(m));   // m >= 0: uint order == float order
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) sh_m[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float bm = sh_m[0];
+        for (int i = 1; i < FK_THREADS / 64; ++i) bm = fmaxf(bm, sh_m[i]);
+        r->amax = bm;
+        r->E = E;
+        r->count = sh_cnt <= FK_CAP ? sh_cnt : -1;
+    }
+    }
+}
+
+// GSMCAL_CERT=0 (or a geometry the certificate does not cover): every chunk of every window is open.
+// grid (H, S), block 64.
+__global__ void k_fine_openall(const StreamState* __restrict__ sts, int nchunk, int H, int* __restrict__ items,
+                               int* __restrict__ n_items) {
+    const int s = blockIdx.y, w = blockIdx.x;
+    if (w >= sts[s].n_win) return;
+    __shared__ int base;
+    if (threadIdx.x == 0) base = atomicAdd(n_items, nchunk);
+    __syncthreads();
+    for (int c = threadIdx.x; c < nchunk; c += blockDim.x) items[base + c] = ((s * H + w) << 8) | c;
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fine_verify: the exact (fp64) half of the fine search.  grid (H, S), block 256.
-// Work items = (candidate bin k, chunk c) pairs from the prescreen.  For each item the spectrum value
-// at the chunk's first shift is anchored by a direct fp64 DFT (all 64 lanes of a wave, fixed summation
-// order, table twiddles), then one lane slides through the chunk's 64 shifts with the fp64 recurrence
-// tracking (max power, first shift).  The block reduces with MATLAB's first-max rule (larger power, then
-// smaller shift, then smaller bin) into one PeakOut per window.
-// LDS: the 2208-sample window | item anchors | item list | per-bin chunk masks.
+// k_fine_verify: the exact (fp64) last word of the fine search.  grid (H, S), block 256.
+// Work items = the (bin, chunk) pairs k_fine_chunk listed and that reach the window-wide bar L.  For each item the
+// spectrum value at the chunk's first shift is anchored by a direct fp64 DFT (all 64 lanes of a wave, fixed
+// summation order, table twiddles), then one lane slides through the chunk's 64 shifts with the fp64 recurrence
+// tracking (max power, first shift).  The block reduces with MATLAB's first-max rule (larger power, then smaller
+// shift, then smaller bin), the certificate's (P*, t*, k*) competing, into one PeakOut per window.
+// LDS: the window | item anchors | item list.
 // ------------------------------------------------------------------------------------------------
-#define FV_BINS 16                               /* bins per batch */
-#define FV_MAX_ITEMS (FV_BINS * PS_NCHUNK * 2)     /* >= FV_BINS * nchunk for ov <= 16 */
+#define FV_MAX_ITEMS 512
 __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
                                                      const cplx* __restrict__ win, long win_stream_stride,
                                                      long win_stride, int nshift, int nfft,
-                                                     const cplx* __restrict__ tw_g, const float* __restrict__ p32,
-                                                     const unsigned short* __restrict__ cmask,
-                                                     const unsigned int* __restrict__ pmax32,
-                                                     const double* __restrict__ esum, PeakOut* __restrict__ out, int H,
-                                                     const FineCert* __restrict__ cert) {
+                                                     const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
+                                                     PeakOut* __restrict__ out, int H,
+                                                     const FineCert* __restrict__ cert, int* __restrict__ n_open) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_open = 0;   // k_fine_chunk is done with the list: clear it for the next batch
     const int wlen = nshift - 1 + nfft;
     cplx* xs = (cplx*)smem;                               // window
     cplx* anchor = xs + wlen;                             // X_k at the chunk's first shift, per item
     int* items = (int*)(anchor + FV_MAX_ITEMS);           // (k << 8) | chunk
-    unsigned short* cm_s = (unsigned short*)(items + FV_MAX_ITEMS);   // list of candidate bins
-    __shared__ int n_items, n_cand;
+    __shared__ int n_items, n_over;
     __shared__ double red_p[4];
     __shared__ int red_t[4], red_k[4];
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nstep = nshift - 1;
+    const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
     FineCert fc;
-    fc.p = -1.0; fc.t = 0x7fffffff; fc.k = 0x7fffffff; fc.nch = -1;
+    fc.p = -1.0; fc.t = 0x7fffffff; fc.k = 0x7fffffff; fc.nch = nchunk;
     if (cert) {
         fc = cert[(size_t)s * H + w];
         if (fc.nch == 0) {                                // fully certified window: the certificate IS the answer
@@ -778,77 +807,78 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
             return;
         }
     }
+    const int nopen = fc.nch;
+    const ChunkRec* r = rec + ((size_t)s * H + w) * nchunk;
+    // the bar a pair must reach: the certificate's exact maximum, or the best guaranteed amplitude of any open chunk
+    double L = fc.p > 0.0 ? sqrt(fc.p) : 0.0;
+    for (int c = 0; c < nopen; ++c) {
+        const double v = sqrt((double)r[c].amax) - r[c].E;
+        if (v > L) L = v;
+    }
+    L *= 1.0 - 1e-9;
+    if (tid == 0) { n_items = 0; n_over = 0; }
+    __syncthreads();
+    for (int i = tid; i < nopen * FK_CAP; i += 256) {     // listed candidates of all open chunks
+        const int c = i / FK_CAP, q = i - c * FK_CAP;
+        const int cnt = r[c].count;
+        if (cnt < 0) { if (q == 0) atomicAdd(&n_over, 1); continue; }
+        if (q >= cnt) continue;
+        const ChunkCand cc = r[c].cand[q];
+        if (sqrt((double)cc.p) + r[c].E >= L) {
+            const int idx = atomicAdd(&n_items, 1);
+            if (idx < FV_MAX_ITEMS) items[idx] = (cc.k << 8) | c;
+        }
+    }
+    __syncthreads();
+    const bool slow = n_over > 0 || n_items > FV_MAX_ITEMS;   // block-uniform; pathological inputs only (e.g. all zeros)
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    if (tid == 0) n_items = 0;
-    for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
-    __syncthreads();
-    const size_t o = ((size_t)s * H + w) * nfft;
-    const double E = FS_ERR_SCALE * esum[(size_t)s * H + w];
-    // the bar a bin must reach: the window's fp32 maximum over the swept chunks, or the certificate's exact
-    // maximum over its own bins (all shifts) if that is higher
-    double amax = sqrt((double)__uint_as_float(pmax32[(size_t)s * H + w]));
-    if (fc.p > 0.0 && sqrt(fc.p) > amax) amax = sqrt(fc.p);
-    const int nstep = nshift - 1;
-    const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
-    // compact list of the candidate bins (amplitude within 2E of the window's fp32 maximum); cm_s[i] = bin
-    if (tid == 0) n_cand = 0;
-    __syncthreads();
-    for (int k = tid; k < nfft; k += 256)
-        if (sqrt((double)p32[o + k]) >= amax - 2.0 * E) cm_s[atomicAdd(&n_cand, 1)] = (unsigned short)k;
-    __syncthreads();
-    const int ncand = n_cand;
     double best = -1.0;
     int bt = 0x7fffffff, bk = 0x7fffffff;
     if (tid == 0 && fc.p > 0.0) { best = fc.p; bt = fc.t; bk = fc.k; }   // the certificate's bins compete with the rest
-    // candidate bins are processed FV_BINS at a time, so the item list can never overflow whatever the input
-    // (an all-zero window makes every bin and chunk a candidate); normally there are 1-3 candidates: one pass
-    for (int kb = 0; kb < ncand; kb += FV_BINS) {
+    if (n_items > 0 || slow) {
+        for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
         __syncthreads();
-        if (tid == 0) n_items = 0;
-        __syncthreads();
-        if (tid < FV_BINS && kb + tid < ncand) {
-            const int k = cm_s[kb + tid];
-            const unsigned mk = cmask[o + k];
-            for (int c = 0; c < nchunk; ++c) {
-                const int bit = c < PS_NCHUNK - 1 ? c : PS_NCHUNK - 1;
-                if (mk & (1u << bit)) {
-                    const int idx = atomicAdd(&n_items, 1);
-                    if (idx < FV_MAX_ITEMS) items[idx] = (k << 8) | c;
+        // normal case: one round over the listed items.  slow case: every (bin, open chunk) pair, FV_MAX_ITEMS at a time
+        const long total = slow ? (long)nopen * nfft : (long)n_items;
+        for (long base = 0; base < total; base += FV_MAX_ITEMS) {
+            const int ni = (int)(total - base < FV_MAX_ITEMS ? total - base : FV_MAX_ITEMS);
+            if (slow) {
+                __syncthreads();
+                for (int i = tid; i < ni; i += 256) {
+                    const long g = base + i;
+                    items[i] = ((int)(g % nfft) << 8) | (int)(g / nfft);
                 }
+                __syncthreads();
             }
-        }
-        __syncthreads();
-        const int ni = n_items < FV_MAX_ITEMS ? n_items : FV_MAX_ITEMS;   // nchunk <= 2*PS_NCHUNK is checked on the host
-        if (ni == 0) continue;                               // block-uniform
-        // ---- anchors: wave-parallel direct DFT, item i handled by wave i % 4 ----
-        for (int i = wave; i < ni; i += 4) {
-            const int k = items[i] >> 8, c = items[i] & 0xFF;
-            const int t0 = c * FS_CHUNK;
-            const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
-            const double ar = av.x, ai = av.y;
-            if (lane == 0) anchor[i] = make_double2(ar, ai);
-        }
-        __syncthreads();
-        // ---- slides: one lane per item ----
-        for (int i = tid; i < ni; i += 256) {
-            const int k = items[i] >> 8, c = items[i] & 0xFF;
-            double wi, wr;
-            sincospi(2.0 * (double)k / (double)nfft, &wi, &wr);
-            double xr = anchor[i].x, xi = anchor[i].y;
-            const int t0 = c * FS_CHUNK;
-            if (c == 0) {                                    // the start window m = 0 belongs to chunk 0
-                const double p = xr * xr + xi * xi;
-                if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
+            // ---- anchors: wave-parallel direct DFT, item i handled by wave i % 4 ----
+            for (int i = wave; i < ni; i += 4) {
+                const int k = items[i] >> 8, c = items[i] & 0xFF;
+                const cplx av = anchor_dft(xs + c * FS_CHUNK, k, tw_g, nfft, lane);
+                const double ar = av.x, ai = av.y;
+                if (lane == 0) anchor[i] = make_double2(ar, ai);
             }
-            const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
-            for (int j = 0; j < lim; ++j) {
-                const cplx a = xs[t0 + j + nfft], b = xs[t0 + j];
-                const double ar = xr + (a.x - b.x), ai = xi + (a.y - b.y);
-                xr = ar * wr - ai * wi;
-                xi = ar * wi + ai * wr;
-                const double p = xr * xr + xi * xi;
-                const int m = t0 + j + 1;
-                if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+            __syncthreads();
+            // ---- slides: one lane per item ----
+            for (int i = tid; i < ni; i += 256) {
+                const int k = items[i] >> 8, c = items[i] & 0xFF;
+                const cplx wk = tw_g[k];
+                const double wr = wk.x, wi = -wk.y;
+                double xr = anchor[i].x, xi = anchor[i].y;
+                const int t0 = c * FS_CHUNK;
+                if (c == 0) {                                    // the start window m = 0 belongs to chunk 0
+                    const double p = xr * xr + xi * xi;
+                    if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
+                }
+                const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
+                for (int j = 0; j < lim; ++j) {
+                    const cplx a = xs[t0 + j + nfft], b = xs[t0 + j];
+                    const double ar = xr + (a.x - b.x), ai = xi + (a.y - b.y);
+                    xr = ar * wr - ai * wi;
+                    xi = ar * wi + ai * wr;
+                    const double p = xr * xr + xi * xi;
+                    const int m = t0 + j + 1;
+                    if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+                }
             }
         }
     }
@@ -915,8 +945,8 @@ __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
 __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict__ sts,
                                                    const cplx* __restrict__ win, long win_stream_stride,
                                                    long win_stride, int nshift, int nfft,
-                                                   const cplx* __restrict__ tw_g, const int* __restrict__ fc_lo,
-                                                   FineCert* __restrict__ cert, int H) {
+                                                   const cplx* __restrict__ tw_g, FineCert* __restrict__ cert, int H,
+                                                   int* __restrict__ items, int* __restrict__ n_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nstep = nshift - 1, wlen = nstep + nfft;
     const int B = fc_gcd64(nfft), nA = nfft / B, nM = wlen / B, nchunk = nstep / FS_CHUNK;
@@ -934,14 +964,63 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     __shared__ double red_p[8];
     __shared__ int red_t[8], red_k[8];
     __shared__ double sh_scan[8], sh_scan2[8];
-    __shared__ int sh_a, sh_b;
+    __shared__ int sh_a, sh_b, sh_lo;
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < wlen; i += nthr) xs[i] = x[i];
     if (tid == 0) { sh_a = 0; sh_b = nstep; }
-    const int lo = fc_lo[(size_t)s * H + w];              // bins lo .. lo+FC_NB-1 (mod nfft), from k_fft_burst<1>
+    __syncthreads();
+    // ---- S: the tone's bin from a 148-point spectrum of the window's middle nfft samples summed in groups of
+    // ov (nfft = 148*ov, so the two frequency grids coincide; the channel filter keeps the signal inside the
+    // decimated band).  Only the choice of S depends on this estimate, never the result: a poor choice just
+    // certifies less.
+    {
+        const int D = nfft / 148, n0 = nstep / 2;
+        cplx* yd = Sp;                                    // region 1 is free until level 1
+        cplx* t148 = Sp + 148;
+        double* pw = (double*)(Sp + 296);
+        for (int m = tid; m < 148; m += nthr) {
+            double sr = 0.0, si = 0.0;
+            for (int i = 0; i < D; ++i) { const cplx v = xs[n0 + D * m + i]; sr += v.x; si += v.y; }
+            yd[m] = make_double2(sr, si);
+            t148[m] = tw_g[D * m];
+        }
+        __syncthreads();
+        for (int q = tid; q < 148; q += nthr) {
+            double ar = 0.0, ai = 0.0;
+            int idx = 0;
+#pragma unroll 4
+            for (int m = 0; m < 148; ++m) {
+                const cplx v = yd[m], t = t148[idx];
+                ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+                ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+                idx += q;
+                idx = idx >= 148 ? idx - 148 : idx;
+            }
+            pw[q] = ar * ar + ai * ai;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double bp = -1.0;
+            int bq = 0;
+            for (int q = lane; q < 148; q += 64)
+                if (pw[q] > bp) { bp = pw[q]; bq = q; }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double op = __shfl_down(bp, off, 64);
+                const int oq = __shfl_down(bq, off, 64);
+                if (op > bp || (op == bp && oq < bq)) { bp = op; bq = oq; }
+            }
+            if (lane == 0) {
+                const bool up = pw[(bq + 1) % 148] > pw[(bq + 147) % 148];
+                const int kpk = bq < 74 ? bq : nfft - 148 + bq;
+                sh_lo = kpk - (up ? FC_NB / 2 - 1 : FC_NB / 2);   // bins lo .. lo+FC_NB-1 (mod nfft), leaning to the stronger side
+            }
+        }
+        __syncthreads();
+    }
+    const int lo = sh_lo;
     const int j = tid & (FC_NB - 1), c = tid / FC_NB;
     const bool act = c < nchunk;                          // lanes beyond the last chunk only help with the shared phases
     const int k = ((lo + j) % nfft + nfft) % nfft;
@@ -1139,6 +1218,10 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (sh_b < nstep || a > bt) o.nch = nchunk;       // a suffix (or everything) is open: sweep the whole window
         else o.nch = a == 0 ? 0 : (a == 1 ? 1 : (a - 2) / FS_CHUNK + 1);   // chunk c holds shifts 64c+1..64c+64 (+ shift 0)
         cert[(size_t)s * H + w] = o;
+        if (o.nch > 0) {                                  // work list of k_fine_chunk
+            const int base = atomicAdd(n_items, o.nch);
+            for (int i = 0; i < o.nch; ++i) items[base + i] = ((s * H + w) << 8) | i;
+        }
     }
 }
 
