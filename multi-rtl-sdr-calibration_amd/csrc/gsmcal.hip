@@ -480,6 +480,14 @@ int fir_decim_raw(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const doub
 // batch front end: one pass over the raw bytes (per-block byte sums + FIR of the raw samples).  The means are
 // formed from the partial sums by the coarse kernels, and k_coarse_scan builds each stream's state from scratch,
 // so the batch path needs neither a memset of the state array nor a separate mean kernel.
+// the two instances of the register-row front kernel (named so that profiles show them apart)
+static const auto k_front_fast47_sym = &k_front_fast<47, true>;
+static const auto k_front_fast47 = &k_front_fast<47, false>;
+static const auto k_front_fast31_sym = &k_front_fast<31, true>;
+static const auto k_front_fast31 = &k_front_fast<31, false>;
+
+static inline int lds_pad_host(int rel) { return rel + ((rel >> 6) << 3); }
+
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                 cplx* d_out, long out_stride) {
     const long nd = (n + decim - 1) / decim;
@@ -488,13 +496,24 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
     if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
     const unsigned nblk = (unsigned)((nd + 255) / 256);
     RET_IF(ensure(c, c->cur->state, (size_t)S * sizeof(StreamState)));
-    RET_IF(ensure(c, c->cur->partial, (size_t)S * nblk * 2 * sizeof(unsigned long long)));
+    RET_IF(ensure(c, c->cur->partial, (size_t)S * nblk * 4 * 2 * sizeof(unsigned long long)));
     c->cur->npartial = (int)nblk;
     c->last_S = S;
     bool sym = (int)c->h_coef.size() == ntaps;                 // linear-phase taps? (fir1 and the .fda designs are)
     for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
-    LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef,
-           ntaps, decim, nd, d_out, out_stride, sym ? 1 : 0);
+    if ((ntaps == 47 || ntaps == 31) && decim == 64 && ((uintptr_t)d_raw & 15) == 0 && ((2 * n) & 15) == 0 &&
+        !getenv("GSMCAL_FRONT_GENERIC")) {
+        // the production geometries (fir1(46) / fir1(30), 8x oversampling, aligned captures): rows in registers
+        const size_t flds = ((size_t)lds_pad_host(8 * 2048) * 2 + 15) & ~(size_t)15;
+        c->cur->npartial = (int)nblk * 4;                  // this kernel writes one partial per wave
+#define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef, nd, d_out, out_stride)
+        if (ntaps == 47) { if (sym) FRONT_FAST(k_front_fast47_sym); else FRONT_FAST(k_front_fast47); }
+        else { if (sym) FRONT_FAST(k_front_fast31_sym); else FRONT_FAST(k_front_fast31); }
+#undef FRONT_FAST
+    } else {
+        LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef,
+               ntaps, decim, nd, d_out, out_stride, sym ? 1 : 0);
+    }
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -700,6 +719,10 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_fine_cert, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fast47_sym, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fast47, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fast31_sym, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_front_fast31, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);

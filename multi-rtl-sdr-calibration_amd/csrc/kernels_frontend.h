@@ -334,6 +334,132 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_front_fast<NT>: k_front_fused for the production geometry -- NT odd linear-phase taps (NT <= 49), decimation
+// 64, every stream starting on a 16-byte boundary.  Same outputs (per-block byte sums + FIR of the raw samples),
+// but the VALU work per sample is a third: the block's 256 rows of 64 samples are staged through LDS only to
+// turn the coalesced global reads into one contiguous 128-byte row per lane; each lane then holds its row in
+// 32 registers and
+//   * takes the row's I/Q byte sums with v_dot4_u32_u8 (2 per dword),
+//   * forms each tap pair's integer sum a+b with two v_dot4_u32_u8 (compile-time byte selectors), converts
+//     once and issues one fp64 FMA per pair and component.
+// Row t of block j0 = samples [64(j0+t)-48, 64(j0+t)+16): it contains the NT taps of output j0+t (samples
+// 64j-NT+1 .. 64j) and the rows tile the stream, so the byte sums of the rows are the stream's sums (the last
+// block adds the <= 48 samples past its last row).  Samples outside [0, n) are staged as zeros: zero initial
+// state of filter(), and nothing for the sums.
+// grid (ceil(nd/256), S), block 256.  LDS: 2048 chunks of 8 samples, rows padded to 144 bytes; partial sums: 4 per block.
+// ------------------------------------------------------------------------------------------------
+#define FFAST_CHUNKS (2048 + 6)
+__device__ __forceinline__ uint4 ffast_chunk(const unsigned short* __restrict__ base, long g0, long n) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);                   // 8 samples from g0, zeros outside [0, n)
+    if (g0 >= 0 && g0 + 8 <= n) {
+        v = *(const uint4*)(base + g0);
+    } else if (g0 + 8 > 0 && g0 < n) {                      // straddles an end of the stream
+        unsigned short q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = (g0 + i >= 0 && g0 + i < n) ? base[g0 + i] : (unsigned short)0;
+        v.x = q[0] | ((unsigned)q[1] << 16); v.y = q[2] | ((unsigned)q[3] << 16);
+        v.z = q[4] | ((unsigned)q[5] << 16); v.w = q[6] | ((unsigned)q[7] << 16);
+    }
+    return v;
+}
+
+template <int NT, bool SYM>
+__global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ raw, long stream_bytes,
+                                                    unsigned long long* __restrict__ partial,
+                                                    const double* __restrict__ coef, long nd,
+                                                    cplx* __restrict__ out, long out_stride) {
+    static_assert((NT & 1) == 1 && NT <= 49, "odd tap count that fits the 56-sample register window");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* r_s = (unsigned short*)smem;
+    const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long n = stream_bytes >> 1;
+    const unsigned short* base = (const unsigned short*)(raw + (size_t)s * stream_bytes);
+    const long j0 = (long)blockIdx.x * 256;
+    long jn = nd - j0;
+    if (jn > 256) jn = 256;
+    const long first_al = 64 * j0 - 48;                     // sample at row 0, position 0 (16-byte aligned in memory)
+    // Each WAVE stages its own 64 rows (512 chunks, one contiguous 8 KB piece of the stream) and reads back only
+    // those: LDS operations of one wave execute in order, so no block barrier is needed and the four waves of a
+    // block drift apart freely (loads of one overlap the arithmetic of another).
+    {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ffast_chunk(base, first_al + 8L * (512 * wave + lane + 64 * u), n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *(uint4*)(r_s + lds_pad(8 * (512 * wave + lane + 64 * u))) = v[u];
+    }
+    unsigned w[32];                                         // this lane's row
+    {
+        const uint4* rp = (const uint4*)(r_s + lds_pad(64 * t));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint4 q = rp[u];
+            w[4 * u] = q.x; w[4 * u + 1] = q.y; w[4 * u + 2] = q.z; w[4 * u + 3] = q.w;
+        }
+    }
+    unsigned si = 0, sq = 0;                                // sample = I | Q<<8, two samples per dword
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        si = __builtin_amdgcn_udot4(w[i], 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(w[i], 0x01000100u, sq, false);
+    }
+    if (blockIdx.x == gridDim.x - 1 && t < FFAST_CHUNKS - 2048) {   // the samples past the last row of the stream's last block
+        const uint4 q = ffast_chunk(base, first_al + 8L * (2048 + t), n);
+        const unsigned e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            si = __builtin_amdgcn_udot4(e[i], 0x00010001u, si, false);
+            sq = __builtin_amdgcn_udot4(e[i], 0x01000100u, sq, false);
+        }
+    }
+    {   // exact byte sums per wave; consumers add the 4*gridDim.x partials of the stream (integers: any order)
+        unsigned long long ti = si, tq = sq;
+        for (int off = 32; off > 0; off >>= 1) {
+            ti += __shfl_down(ti, off, 64);
+            tq += __shfl_down(tq, off, 64);
+        }
+        if (lane == 0) {
+            unsigned long long* p = partial + (((size_t)s * gridDim.x + blockIdx.x) * 4 + wave) * 2;
+            p[0] = ti;
+            p[1] = tq;
+        }
+    }
+    if (t >= jn) return;
+    const double* __restrict__ c_s = coef;                  // uniform, compile-time indices: scalar loads
+    // ---- FIR of the raw samples.  Output sample 64j sits at row position 48, tap k at position 48 - k.
+    double ar = 0.0, ai = 0.0;
+    if (SYM) {
+        // exactly symmetric taps (coef[k] == coef[NT-1-k], checked on the host): oldest pair first, the two samples
+        // of a pair added as integers (the order of k_front_fused's symmetric loop)
+#pragma unroll
+        for (int k = 0; k < NT / 2; ++k) {
+            const int ia = 49 - NT + k, ib = 48 - k;
+            const unsigned selIa = (ia & 1) ? 0x00010000u : 0x00000001u, selIb = (ib & 1) ? 0x00010000u : 0x00000001u;
+            const unsigned pi = __builtin_amdgcn_udot4(w[ib >> 1], selIb, __builtin_amdgcn_udot4(w[ia >> 1], selIa, 0u, false), false);
+            const unsigned pq = __builtin_amdgcn_udot4(w[ib >> 1], selIb << 8, __builtin_amdgcn_udot4(w[ia >> 1], selIa << 8, 0u, false), false);
+            const double c = c_s[k];
+            ar = fma(c, (double)pi, ar);
+            ai = fma(c, (double)pq, ai);
+        }
+        const int im = 49 - NT + NT / 2;                    // the middle tap
+        const unsigned smp = (w[im >> 1] >> ((im & 1) * 16)) & 0xFFFFu;
+        ar = fma(c_s[NT / 2], (double)(smp & 0xFF), ar);
+        ai = fma(c_s[NT / 2], (double)(smp >> 8), ai);
+    } else {
+        // any taps: oldest tap first, one conversion and one FMA per tap and component (k_front_fused's order)
+#pragma unroll
+        for (int k = NT - 1; k >= 0; --k) {
+            const int ip = 48 - k;
+            const unsigned smp = w[ip >> 1] >> ((ip & 1) * 16);
+            const double c = c_s[k];
+            ar = fma(c, (double)(smp & 0xFFu), ar);
+            ai = fma(c, (double)((smp >> 8) & 0xFFu), ai);
+        }
+    }
+    out[(size_t)s * out_stride + j0 + t] = make_double2(ar, ai);
+}
+
+// ------------------------------------------------------------------------------------------------
 // filter(coef,1,s) on a complex array, keeping rows 1:decim:end.  grid (ceil(nd/256), D).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fir_arr(const cplx* __restrict__ in, long in_stride, long n,

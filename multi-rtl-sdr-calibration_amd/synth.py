@@ -87,6 +87,10 @@ def fir1(n, wn):
     h = wn * np.sinc(wn * m)
     w = 0.54 - 0.46 * np.cos(2.0 * math.pi * k / n)
     h = h * w
+    # MATLAB builds both the ideal response and the window as one half plus its mirror image, so the taps it
+    # returns are symmetric to the last bit; do the same (the HIP front end has a faster kernel for such taps)
+    half = (n + 1) // 2
+    h[n + 1 - half:] = h[:half][::-1]
     return h / np.sum(h)
 
 
