@@ -305,6 +305,16 @@ def bench_scan(args, rank, world, dev, use_dist):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    prof = {}
+    if not args.no_kernel_events and rank == 0:     # untimed pass: per-kernel breakdown (HIP events on the launch stream)
+        ctx.profile_reset()
+        ctx.profile_filter(None)
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
     res = out_t.cpu().numpy()
     value = world * D * N * args.steps / elapsed / 1e6
     out = {"metric": "IQ Msamples/s through FCCH scanner path", "value": round(value, 3), "unit": "Msample/s",
@@ -316,6 +326,18 @@ def bench_scan(args, rank, world, dev, use_dist):
                       "captures_with_hits": int(np.sum(res[:, 1] > 0)), "bytes_per_sample_algorithmic": 2.25},
            "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1)}
     if rank == 0:
+        if prof:
+            out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / args.steps, 4)
+                                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            for k, v in prof.items():
+                if k.startswith("k_front") and v[1]:
+                    ms = v[0] / v[1]
+                    per_launch = D * N * 2.25 * args.steps / v[1]     # the batch may be split over internal lanes
+                    ach = per_launch / 1e9 / (ms * 1e-3)
+                    out["roofline"] = {"kernel": k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "avg_launch_ms": round(ms, 5),
+                                       "note": "2 B/sample raw read + 16/64 B/sample decimated complex-double write"}
         if not args.no_cpu_baseline and world == 1:
             from oracle import gsmcal_oracle as oracle
             t_cpu, done = 0.0, 0

@@ -42,7 +42,7 @@ struct ProfRec {
 #define MAX_LANES 8
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial;
+    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
@@ -263,6 +263,18 @@ size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
     return ((size_t)g.nfft + (size_t)37 * (g.nfft / 37 + 1) + 40 + g.nfft / 37) * sizeof(cplx);
 }
 
+// decision steps that ride on a per-window kernel (stream_tail): one self-re-arming counter per stream
+int make_tail(gsmcal_ctx* c, int S, const StepArgs& sa, int steps, int lvl_a, int lvl_b, TailArgs& t) {
+    const size_t need = (size_t)S * sizeof(unsigned);
+    if (c->cur->tailctr.cap < need) {
+        RET_IF(ensure(c, c->cur->tailctr, need));
+        HIPCHK(c, hipMemsetAsync(c->cur->tailctr.p, 0, c->cur->tailctr.cap, c->cur->stream));
+    }
+    t.ctr = (unsigned*)c->cur->tailctr.p;
+    t.steps = steps; t.lvl_a = lvl_a; t.lvl_b = lvl_b; t.sa = sa;
+    return 0;
+}
+
 StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
     StepArgs a;
     memset(&a, 0, sizeof(a));
@@ -320,9 +332,12 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->tw.p, certp,
                (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
         const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) + 15) & ~(size_t)15;
-        LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-               g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const ChunkRec*)c->cur->chunkrec.p, peaks, H, certp, n_open);
         sa_fine.NB = 1;
+        TailArgs tl;
+        RET_IF(make_tail(c, S, sa_fine, STEP_FINE_DECIDE, lvl, 0, tl));
+        LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+               g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const ChunkRec*)c->cur->chunkrec.p, peaks, H, certp, n_open,
+               st, tl);
     } else {
         RET_IF(ensure(c, c->cur->x0, (size_t)S * H * g.nfft * sizeof(cplx)));
         LAUNCH(c, k_fft_burst<1>, dim3(H, S), dim3(FFT_THREADS), fft_lds(g), (const StreamState*)st, (const cplx*)win, sstride,
@@ -330,6 +345,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         LAUNCH(c, k_fine_search, dim3(g.NB, H, S), dim3(256), (size_t)(g.fine_nshift - 1 + FS_CHUNK) * sizeof(cplx),
                (const StreamState*)st, (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->cur->x0.p,
                peaks, H, g.NB);
+        LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa_fine, lvl, 0);
     }
     if (c->prescreen && c->certify && getenv("GSMCAL_DBG_CERT") && c->cur->cert.p) {   // histogram of the certificate's open chunks
         (void)hipStreamSynchronize(c->cur->stream);
@@ -350,15 +366,19 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         for (int i = 0; i < 34; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
         fprintf(stderr, "\n");
     }
-    LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa_fine, lvl, 0);
     // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
     // and SNR gate fused per burst
     {
         const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
+        TailArgs tl;   // FCCH_fine_correction's carrier decision (+ the SCH stage's window setup) rides on the last burst
+        RET_IF(make_tail(c, S, sa, next_sch_lvl >= 0 ? (STEP_CARRIER_DECIDE | STEP_SCH_SETUP) : STEP_CARRIER_DECIDE, lvl,
+                         next_sch_lvl >= 0 ? next_sch_lvl : 0, tl));
         LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov, 1);
+               g.nfft, (const cplx*)c->tw.p, g.ov, 1, tl);
     }
     if (getenv("GSMCAL_DBG_BT")) {
+        TailArgs notail;
+        memset(&notail, 0, sizeof(notail));
         const size_t nb = (size_t)S * H;
         RET_IF(ensure(c, c->misc, nb * 16 * 8));
         (void)hipStreamSynchronize(c->cur->stream);
@@ -367,7 +387,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_dbg), &p, sizeof(p));
         const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
         LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov, 1);
+               g.nfft, (const cplx*)c->tw.p, g.ov, 1, notail);
         (void)hipStreamSynchronize(c->cur->stream);
         std::vector<unsigned long long> h(nb * 16);
         (void)hipMemcpy(h.data(), p, h.size() * 8, hipMemcpyDeviceToHost);
@@ -386,10 +406,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         fprintf(stderr, "burst_tone<1>: %d blocks, span %.1f us; mean phase us: gather %.1f fft+argmax %.1f tone %.1f gate %.1f\n",
                 cnt, (t1 - t0) / 100.0, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
     }
-    if (next_sch_lvl >= 0)
-        LAUNCH(c, k_step<STEP_CARRIER_DECIDE | STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_sch_lvl);
-    else
-        LAUNCH(c, k_step<STEP_CARRIER_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -407,13 +423,12 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
     {
         const GatherArgs ga = gather_args(src, lvl, wl);
         const size_t scratch = (size_t)(len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+        TailArgs tl;   // SCH_corr_rate_correction's decisions (+ the post stage's window setup) ride on the last window
+        RET_IF(make_tail(c, S, sa, next_post_lvl >= 0 ? (STEP_SCH_DECIDE | STEP_POST_SETUP) : STEP_SCH_DECIDE, lvl,
+                         next_post_lvl >= 0 ? next_post_lvl : 0, tl));
         LAUNCH(c, k_window_sch, dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
-               len_ts, g.sch_nshift);
+               len_ts, g.sch_nshift, tl);
     }
-    if (next_post_lvl >= 0)
-        LAUNCH(c, k_step<STEP_SCH_DECIDE | STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, next_post_lvl);
-    else
-        LAUNCH(c, k_step<STEP_SCH_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -434,13 +449,11 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     {
         const GatherArgs ga = gather_args(src, lvl, g.nfft);
+        TailArgs tl;   // carrier_correct_post_SCH's decision (+ the calibration table row) rides on the last burst
+        RET_IF(make_tail(c, S, sa, table ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, lvl, 0, tl));
         LAUNCH(c, k_burst_tone<0>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov, 0);
+               g.nfft, (const cplx*)c->tw.p, g.ov, 0, tl);
     }
-    if (table)
-        LAUNCH(c, k_step<STEP_POST_DECIDE | STEP_TOTALS>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
-    else
-        LAUNCH(c, k_step<STEP_POST_DECIDE>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -607,8 +620,11 @@ int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
 }
 
 // Split d units over the lanes: returns the number of lanes used and fills lo/n per lane.
-int plan_lanes(gsmcal_ctx* c, int d) {
-    int nl = c->n_lanes_cfg;
+int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
+    // lanes pay off where the chain is a string of short latency-bound kernels (calibration); the scanner path is
+    // two bandwidth-bound kernels that only get in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms
+    // for 12,800 captures)
+    int nl = latency_bound ? c->n_lanes_cfg : 1;
     if (nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl < 1) nl = 1;
     for (int i = 0; i < nl; ++i) {
@@ -776,7 +792,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1191,7 +1207,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
                                         (uintptr_t)d_snr_numhit, (uintptr_t)d_positions, (uintptr_t)d_pos_snr,
                                         (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg};
     auto enqueue = [&]() -> int {
-    const int nl = plan_lanes(c, d);
+    const int nl = plan_lanes(c, d, false);
     RET_IF(fork_lanes(c, nl));
     for (int i = 0; i < nl; ++i) {
         Lane& L = c->lanes[i];
@@ -1214,7 +1230,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     return 0;
     };
     RET_IF(run_maybe_graph(c, c->g_scan, key, enqueue));
-    plan_lanes(c, d);
+    plan_lanes(c, d, false);
     c->cur = &c->lanes[0];
     c->last_S = d;
     return 0;

@@ -778,13 +778,21 @@ __global__ void k_fine_openall(const StreamState* __restrict__ sts, int nchunk, 
 // LDS: the window | item anchors | item list.
 // ------------------------------------------------------------------------------------------------
 #define FV_MAX_ITEMS 512
-__global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
-                                                     const cplx* __restrict__ win, long win_stream_stride,
-                                                     long win_stride, int nshift, int nfft,
-                                                     const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
-                                                     PeakOut* __restrict__ out, int H,
-                                                     const FineCert* __restrict__ cert, int* __restrict__ n_open) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// (agent-scope stores: the workgroup that runs the stream's decision step in this same kernel reads them)
+__device__ __forceinline__ void peak_store(PeakOut* dst, const PeakOut& o) {
+    static_assert(sizeof(PeakOut) == 16, "two 64-bit words");
+    unsigned long long* d = (unsigned long long*)dst;
+    __hip_atomic_store(d, (unsigned long long)__double_as_longlong(o.p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, (unsigned long long)(unsigned)o.tie | ((unsigned long long)(unsigned)o.k << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__ sts,
+                                                 const cplx* __restrict__ win, long win_stream_stride,
+                                                 long win_stride, int nshift, int nfft,
+                                                 const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
+                                                 PeakOut* __restrict__ out, int H,
+                                                 const FineCert* __restrict__ cert, int* __restrict__ n_open,
+                                                 unsigned char* smem) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_open = 0;   // k_fine_chunk is done with the list: clear it for the next batch
     const int wlen = nshift - 1 + nfft;
     cplx* xs = (cplx*)smem;                               // window
@@ -803,7 +811,7 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
     if (cert) {
         fc = cert[(size_t)s * H + w];
         if (fc.nch == 0) {                                // fully certified window: the certificate IS the answer
-            if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; out[(size_t)s * H + w] = o2; }
+            if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; peak_store(&out[(size_t)s * H + w], o2); }
             return;
         }
     }
@@ -896,7 +904,7 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
                 best = red_p[i]; bt = red_t[i]; bk = red_k[i];
             }
         PeakOut o2; o2.p = best; o2.tie = bt; o2.k = bk;
-        out[(size_t)s * H + w] = o2;
+        peak_store(&out[(size_t)s * H + w], o2);
     }
 }
 

@@ -22,6 +22,34 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
     return b;
 }
 
+// Results one workgroup hands to ANOTHER workgroup of the same kernel (stream_tail below) go through agent-scope
+// relaxed atomics: write-through past the XCD's L2 on the store side, cache-bypassing on the load side.  The
+// MI355X has eight L2s; a device-wide fence per workgroup (write back + invalidate) was measured at ~100 us per
+// kernel, these cost nothing.
+__device__ __forceinline__ void coherent_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long coherent_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ PeakOut coherent_peak(const PeakOut* p) {
+    static_assert(sizeof(PeakOut) == 16, "two 64-bit words");
+    const unsigned long long a = coherent_load((const unsigned long long*)p), b = coherent_load((const unsigned long long*)p + 1);
+    PeakOut o;
+    o.p = __longlong_as_double((long long)a);
+    o.tie = (int)(b & 0xffffffffu);
+    o.k = (int)(b >> 32);
+    return o;
+}
+__device__ __forceinline__ PeakOut merge_peaks_coherent(const PeakOut* p, int NB) {
+    PeakOut b = coherent_peak(p);
+    for (int i = 1; i < NB; ++i) {
+        const PeakOut q = coherent_peak(p + i);
+        if (q.p > b.p || (q.p == b.p && q.tie < b.tie)) b = q;
+    }
+    return b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_burst_tone<GATE>: one workgroup per FCCH burst does the whole per-burst estimate without leaving
 // LDS: gather the burst window at level a.level (raw -> raw2iq -> FIR -> lerp [-> mix -> lerp]),
@@ -35,9 +63,9 @@ __device__ __forceinline__ PeakOut merge_peaks(const PeakOut* p, int NB) {
 __device__ unsigned long long* g_bt_dbg = nullptr;   // development aid: per-phase timestamps of k_burst_tone
 #define BT_STAMP(i) do { if (g_bt_dbg && tid == 0) g_bt_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 template <int GATE>
-__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft,
-                                                           const cplx* __restrict__ tw_g, int ov, int prior_mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, const GatherArgs& a, int nfft,
+                                                const cplx* __restrict__ tw_g, int ov, int prior_mode,
+                                                unsigned char* smem) {
     __shared__ double red_p[BT_THREADS / 64];
     __shared__ int red_t[BT_THREADS / 64];
     __shared__ double red[2 * (BT_THREADS / 64)];
@@ -179,7 +207,7 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
         const double cnt = (double)(nfft - 1);
         const double phase = atan2(ti / cnt, tr / cnt);
         sh_phase = phase;
-        st->fo_burst[w] = sampling_rate * (ipr + phase) / TWO_PI_D;   // :155
+        coherent_store(&st->fo_burst[w], sampling_rate * (ipr + phase) / TWO_PI_D);   // :155
     }
     BT_STAMP(3);
     if (!GATE) return;
@@ -220,7 +248,7 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int k = nb - 2; k < nb; ++k) sig += P[k];
         for (int k = 3; k < hnl; ++k) noi += P[k];
         for (int k = hnl; k < nb - 2; ++k) noi += P[k];
-        st->snr_burst[w] = 10.0 * log10(sig / noi);
+        coherent_store(&st->snr_burst[w], 10.0 * log10(sig / noi));
     }
     BT_STAMP(4);
 }
@@ -232,9 +260,9 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
 // Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge (:59).
 // ------------------------------------------------------------------------------------------------
 #define SCH_PARTS 4
-__global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
-                                                    const cplx* __restrict__ ts, int len_ts, int nshift) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, const GatherArgs& a,
+                                                const cplx* __restrict__ ts, int len_ts, int nshift,
+                                                unsigned char* smem) {
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
     if (!xs) return;
@@ -272,7 +300,7 @@ __global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ st
         double mx = cv[0];
         for (int o = 1; o < nshift; ++o)
             if (cv[o] > mx) { mx = cv[o]; mi = o; }
-        st->sch_first[w] = (double)(st->win_start[w] + 1 + mi);   // sp + max_idx - 1
+        coherent_store(&st->sch_first[w], (double)(st->win_start[w] + 1 + mi));   // sp + max_idx - 1
         if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
     }
 }
@@ -643,31 +671,101 @@ enum { STEP_FINE_SETUP = 1, STEP_FINE_DECIDE = 2, STEP_CARRIER_DECIDE = 4, STEP_
 
 // `steps` is a bit set executed in the order of the enum; lvl_a / lvl_b: input level of the first /
 // second step of a merged pair (e.g. carrier_decide works on the fine stage's level, sch_setup on the
-// SCH stage's input level).
+// SCH stage's input level).  Called by every thread of a workgroup (>= 64 threads); `sh` is an LDS copy of the state.
+template <bool COHERENT>
+__device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const StepArgs& a, int steps, int lvl_a,
+                                          int lvl_b, int s, StreamState* sh) {
+    const int lane = threadIdx.x;
+    if (COHERENT) {       // inside the kernel that produced part of the state: read it past the caches
+        const unsigned long long* src = (const unsigned long long*)(sts + s);
+        unsigned long long* dst = (unsigned long long*)sh;
+        for (int i = lane; i < (int)(sizeof(StreamState) / 8); i += blockDim.x) dst[i] = coherent_load(src + i);
+    } else if (lane < 64) {
+        StateLds::load(sh, sts + s, lane);
+    }
+    __syncthreads();
+    if ((steps & STEP_FINE_DECIDE) && lane < sh->n_win && lane < MAXH) {
+        // merge the NB partial peaks of window `lane` (the loads of all windows are in flight together)
+        const PeakOut* pw = a.peaks + ((size_t)s * a.H + lane) * a.NB;
+        const PeakOut pk = COHERENT ? merge_peaks_coherent(pw, a.NB) : merge_peaks(pw, a.NB);
+        sh->fine_first[lane] = (double)(sh->win_start[lane] + 1 + pk.tie);          // sp + max_idx - 1
+        sh->prior_bin[lane] = pk.k;
+    }
+    if (steps & STEP_FINE_DECIDE) __syncthreads();
+    if (lane == 0) {
+        if (steps & STEP_FINE_SETUP) d_fine_setup(sh, s, a.ov, lvl_a);
+        if (steps & STEP_FINE_DECIDE) d_fine_decide(sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);
+        if (steps & STEP_CARRIER_DECIDE) d_carrier_decide(sh, s, a.ov, a.carrier_freq, lvl_a);
+        if (steps & STEP_SCH_SETUP) d_sch_setup(sh, s, a.ov, a.len_ts, lvl_b);
+        if (steps & STEP_SCH_DECIDE) d_sch_decide(sh, s, a.ov, lvl_a);
+        if (steps & STEP_POST_SETUP) d_post_setup(sh, s, a.ov, lvl_b);
+        if (steps & STEP_POST_DECIDE) d_post_decide(sh, s, a.ov, a.carrier_freq, lvl_a);
+        if (steps & STEP_TOTALS) d_totals(sh, s, a.table, a.pos_info_out, a.r_len_out);
+        if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts);
+    }
+    __syncthreads();
+    if (!(steps == STEP_TOTALS || steps == STEP_SCAN_ACCEPT) && lane < 64) StateLds::store(sts + s, sh, lane);
+}
+
 template <int STEPS>
 __global__ void __launch_bounds__(64) k_step(StreamState* __restrict__ sts, StepArgs a, int lvl_a, int lvl_b) {
     __shared__ StreamState sh;
-    const int s = blockIdx.x, lane = threadIdx.x;
-    StateLds::load(&sh, sts + s, lane);
+    step_body<false>(sts, a, STEPS, lvl_a, lvl_b, blockIdx.x, &sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decision steps riding on the per-window kernels.  The per-window kernels run H workgroups per stream; the LAST
+// of them to finish (a per-stream counter, re-armed by that workgroup) runs the stream's decision steps right
+// there, on the LDS its window no longer needs -- no separate one-block-per-stream launch between the stages.
+// Every workgroup of the grid must call stream_tail (also those without a window), with all its threads.
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+    unsigned* ctr;            // one counter per stream, zero between kernels; nullptr: no tail (decisions launched apart)
+    int steps, lvl_a, lvl_b;
+    StepArgs sa;
+};
+
+__device__ __forceinline__ void stream_tail(StreamState* __restrict__ sts, const TailArgs& t, unsigned char* smem) {
+    if (!t.ctr) return;
+    __shared__ int sh_last;
+    // this workgroup's hand-over values were stored write-through (coherent_store); wait until they are acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if ((STEPS & STEP_FINE_DECIDE) && lane < sh.n_win && lane < MAXH) {
-        // merge the NB partial peaks of window `lane` (the loads of all windows are in flight together)
-        const PeakOut pk = merge_peaks(a.peaks + ((size_t)s * a.H + lane) * a.NB, a.NB);
-        sh.fine_first[lane] = (double)(sh.win_start[lane] + 1 + pk.tie);          // sp + max_idx - 1
-        sh.prior_bin[lane] = pk.k;
-    }
-    if (STEPS & STEP_FINE_DECIDE) __syncthreads();
-    if (lane == 0) {
-        if (STEPS & STEP_FINE_SETUP) d_fine_setup(&sh, s, a.ov, lvl_a);
-        if (STEPS & STEP_FINE_DECIDE) d_fine_decide(&sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);
-        if (STEPS & STEP_CARRIER_DECIDE) d_carrier_decide(&sh, s, a.ov, a.carrier_freq, lvl_a);
-        if (STEPS & STEP_SCH_SETUP) d_sch_setup(&sh, s, a.ov, a.len_ts, lvl_b);
-        if (STEPS & STEP_SCH_DECIDE) d_sch_decide(&sh, s, a.ov, lvl_a);
-        if (STEPS & STEP_POST_SETUP) d_post_setup(&sh, s, a.ov, lvl_b);
-        if (STEPS & STEP_POST_DECIDE) d_post_decide(&sh, s, a.ov, a.carrier_freq, lvl_a);
-        if (STEPS & STEP_TOTALS) d_totals(&sh, s, a.table, a.pos_info_out, a.r_len_out);
-        if (STEPS & STEP_SCAN_ACCEPT) d_scan_accept(&sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts);
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(&t.ctr[blockIdx.y], 1u);   // relaxed, agent scope
+        sh_last = old == gridDim.x - 1;
+        if (sh_last) atomicExch(&t.ctr[blockIdx.y], 0u);          // re-arm for the next kernel
     }
     __syncthreads();
-    if (!(STEPS == STEP_TOTALS || STEPS == STEP_SCAN_ACCEPT)) StateLds::store(sts + s, &sh, lane);
+    if (!sh_last) return;                                   // block-uniform
+    step_body<true>(sts, t.sa, t.steps, t.lvl_a, t.lvl_b, blockIdx.y, (StreamState*)smem);
+}
+
+template <int GATE>
+__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft, const cplx* __restrict__ tw_g, int ov, int prior_mode,
+             TailArgs tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    burst_tone_body<GATE>(sts, a, nfft, tw_g, ov, prior_mode, smem);
+    stream_tail(sts, tail, smem);
+}
+
+__global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
+                                                    const cplx* __restrict__ ts, int len_ts, int nshift, TailArgs tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    window_sch_body(sts, a, ts, len_ts, nshift, smem);
+    stream_tail(sts, tail, smem);
+}
+
+__global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
+                                                     const cplx* __restrict__ win, long win_stream_stride,
+                                                     long win_stride, int nshift, int nfft,
+                                                     const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
+                                                     PeakOut* __restrict__ out, int H,
+                                                     const FineCert* __restrict__ cert, int* __restrict__ n_open,
+                                                     StreamState* __restrict__ sts_rw, TailArgs tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fine_verify_body(sts, win, win_stream_stride, win_stride, nshift, nfft, tw_g, rec, out, H, cert, n_open, smem);
+    stream_tail(sts_rw, tail, smem);
 }
