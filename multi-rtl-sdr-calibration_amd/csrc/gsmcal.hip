@@ -538,8 +538,9 @@ int hits_capacity(long len_dec, int dec_ratio) {
     return h;
 }
 
-size_t coarse_scan_lds(long nwin, int mv_len) {
-    return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + (size_t)(nwin + mv_len + 128) * sizeof(double);
+size_t coarse_scan_lds(long nwin, int mv_len, bool speculate = false) {
+    return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) +
+           (speculate ? (size_t)MAXH * (32 * sizeof(double) + 2 * sizeof(long)) : 0) + (size_t)(nwin + mv_len + 128) * sizeof(double);
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
@@ -561,7 +562,10 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
     const long nwin = n_first - (fft_len - 1);
-    const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
+    // few streams: the kernel is a chain of latencies, so a second wave walks the hops speculatively while the first
+    // replays the running sums; many streams: throughput counts, and the table's LDS would cost occupancy
+    a.speculate = S <= 512 ? 1 : 0;
+    const size_t lds = coarse_scan_lds(n_first, 10 * fft_len, a.speculate != 0);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;

@@ -143,6 +143,7 @@ struct CoarseArgs {
     int mean_corr;
     const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
     int npartial; long n0;                    //            and the capture length they divide by
+    int speculate;                            // mode 0, few streams: walk the hops speculatively beside the exact scan
 };
 
 // raw2iq.m:8 from the front kernel's per-block partial sums: exact integer totals, one fp64 divide each
@@ -233,9 +234,13 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
     __shared__ double sh_avg;  // sum/mv_len seen by the hit window
+    __shared__ int sh_pred;    // predicted first hit (approximate sums), INT_MAX if none
+    __shared__ int sh_nspec;   // hops the speculative walk recorded
     StreamState* st = (StreamState*)smem;                 // LDS copy of the stream state
     cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
-    double* snr_s = (double*)(tw + 64);
+    double* spec_v = (double*)(tw + 64);                  // MAXH x 32: candidate SNRs of the speculative hop walk
+    long* spec_nx = (long*)(spec_v + MAXH * 32);          // MAXH x 2: the (nx0, nx1) each row belongs to
+    double* snr_s = a.speculate ? (double*)(spec_nx + MAXH * 2) : spec_v;   // (no table without speculation)
     StreamState* st_g = sts + blockIdx.x;
     double mr0 = 0.0, mi0 = 0.0;
     unsigned long long ti0 = 0, tq0 = 0;
@@ -285,11 +290,34 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
         st->mv_hit_idx = -1.0;
         st->mv_hit_snr = INFINITY;
         sh_hit = 0x7fffffff;
+        sh_pred = 0x7fffffff;
+        sh_nspec = 0;
         if (bad) set_status(st, 3, GSMCAL_E_INDEX);
     }
     __syncthreads();
     int n = 0;
     CS_STAMP(1);
+    // ---- prediction (mode 0): where will the exact running-average scan hit?  Each thread takes a run of
+    // windows, sums the mv_len entries its first window sees directly and slides from there; the sums differ
+    // from the reference's serially rounded ones by ~1e-12, so the predicted first hit is the exact one unless
+    // a window sits within that of the threshold.  Only the SPECULATION below depends on it, never a result.
+    if (!bad && a.mode == 0 && a.speculate) {
+        const int per = (int)((g.nwin + 255) / 256);
+        const int j0 = tid * per, j1 = j0 + per < (int)g.nwin ? j0 + per : (int)g.nwin;
+        if (j0 < j1) {
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            int q = 0;
+            for (; q + 4 <= mv_len; q += 4) { q0 += snr_s[j0 + q]; q1 += snr_s[j0 + q + 1]; q2 += snr_s[j0 + q + 2]; q3 += snr_s[j0 + q + 3]; }
+            for (; q < mv_len; ++q) q0 += snr_s[j0 + q];
+            double sm = (q0 + q1) + (q2 + q3);
+            const double inv = 1.0 / (double)mv_len;
+            for (int j = j0; j < j1; ++j) {
+                if (snr_s[mv_len + j] - sm * inv > th) { atomicMin(&sh_pred, j); break; }
+                sm += snr_s[mv_len + j] - snr_s[j];
+            }
+        }
+        __syncthreads();
+    }
     if (!bad && a.mode != 2) {
         // ---- move_fft_snr_runtime_avg ----
         const long nwin = g.nwin;
@@ -330,6 +358,47 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
                 }
             }
         }
+        else if (tid < 128 && a.mode == 0 && sh_pred != 0x7fffffff) {
+            // ---- wave 1, while wave 0 replays the exact sums: walk the hops of FCCH_coarse_position.m:32-86 from the
+            // PREDICTED hit and keep every candidate SNR it evaluates.  The SNRs are exact (they do not depend on
+            // the prediction); the real walk below takes them from the table whenever it asks for the same windows.
+            const int lane = tid - 64;
+            const int pred = sh_pred;
+            double sm = 0.0;                                     // approximate average the predicted hit sees
+            for (int q = lane; q < mv_len; q += 64) sm += snr_s[pred + q];
+            for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+            const double h_snr = snr_s[mv_len + pred];
+            const double avg_pred = h_snr - (h_snr - sm / (double)mv_len);
+            const int dec = a.decimation_ratio;
+            const long d0 = (long)round(12500.0 / (double)dec), d1 = (long)round(13750.0 / (double)dec);
+            const int max_offset = 5, nt = 2 * max_offset + 1;
+            const long limit = (len - (fft_len - 1)) - max_offset;
+            long cur = pred + 1;
+            int ns = 0;
+            while (ns < MAXH - 1) {
+                const long nx0 = cur + d0, nx1 = cur + d1;
+                if (nx0 > limit) break;
+                double v = -INFINITY;
+                if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
+                else if (lane < 2 * nt && nx1 <= limit)
+                    v = window_snr(s, nx1 - max_offset - 1 + (lane - nt), fft_len, tw);
+                if (lane < 32) spec_v[ns * 32 + lane] = v;
+                if (lane == 0) { spec_nx[2 * ns] = nx0; spec_nx[2 * ns + 1] = nx1; }
+                ++ns;
+                const unsigned long long hits = __ballot(v - avg_pred > th);
+                const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
+                int found;
+                long nxt;
+                if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; }
+                else {
+                    if (nx1 > limit || !h1) break;
+                    found = nt + __ffsll((long long)h1) - 1;
+                    nxt = nx1;
+                }
+                cur = nxt - max_offset + (found >= nt ? found - nt : found);
+            }
+            if (lane == 0) sh_nspec = ns;
+        }
         __syncthreads();
         CS_STAMP(2);
         const int hit = sh_hit;
@@ -368,7 +437,10 @@ __global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ s
                         const long nx0 = cur + d0, nx1 = cur + d1;
                         if (nx0 > limit) break;                              // :49
                         double v = -INFINITY;
-                        if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
+                        const int hs = n - 1;                                // this hop's row of the speculative walk
+                        if (hs < sh_nspec && spec_nx[2 * hs] == nx0 && spec_nx[2 * hs + 1] == nx1) {
+                            if (lane < 2 * nt) v = spec_v[hs * 32 + lane];   // same windows: same SNRs, already computed
+                        } else if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
                         else if (lane < 2 * nt && nx1 <= limit)
                             v = window_snr(s, nx1 - max_offset - 1 + (lane - nt), fft_len, tw);
                         const unsigned long long hits = __ballot(v - hit_avg_snr > th);   // NaN / -inf compare false
