@@ -571,7 +571,8 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
     if (getenv("GSMCAL_DBG_COARSE")) { RET_IF(ensure(c, c->misc, (size_t)S * 64 + 1024)); a.dbg = (unsigned long long*)c->misc.p; }
     LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
-    LAUNCH(c, k_coarse_scan, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    if (a.speculate) LAUNCH(c, k_coarse_scan<2>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    else LAUNCH(c, k_coarse_scan<4>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     if (a.dbg) {
         std::vector<unsigned long long> h((size_t)S * 8);
         (void)hipStreamSynchronize(c->cur->stream);
@@ -743,7 +744,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_front_fast47, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fast31_sym, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fast31, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_coarse_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -957,7 +959,7 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
         a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
         LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
     }
-    LAUNCH(c, k_coarse_scan, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    LAUNCH(c, k_coarse_scan<2>, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     RET_IF(fetch_states(c, 1, v));
     *out = v[0];

@@ -230,7 +230,10 @@ __device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl);   // kern
 // :30) and a ballot picks the first hit.  Updates past a hit are never used -- the `break`.
 // Then the hop loop of FCCH_coarse_position.m:32-86 (both the +10-frame and the +11-frame candidate
 // windows of a hop are evaluated together; the +11 ones are only consulted when the +10 ones miss).
-__global__ void __launch_bounds__(256) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
+// WAVES: minimum waves per SIMD the register allocator must leave room for -- 2 for the latency-bound small batches
+// (no spills, speculative hop walk), 4 for the big ones (four workgroups per CU; the spills sit off the hot chain).
+template <int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
     __shared__ double sh_avg;  // sum/mv_len seen by the hit window
