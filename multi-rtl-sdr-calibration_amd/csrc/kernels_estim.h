@@ -230,7 +230,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     __syncthreads();
     for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], cmul(base[n >> 4], pw[n & 15]));
     __syncthreads();
-    fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
+    fft37_step1_sym(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);   // (the burst itself is not needed again)
     __syncthreads();
     const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
     const int nb = 2 * hnl;
