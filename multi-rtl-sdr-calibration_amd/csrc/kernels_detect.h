@@ -610,6 +610,43 @@ __device__ __forceinline__ cplx fft37_step2_bin(const cplx* B, const cplx* wN2, 
     return make_double2(ar, ai);
 }
 
+// step 2 for a MIRROR PAIR of bins sharing row k1: k = k1 + 37*j and k' = k1 + 37*(N2-j), 1 <= j < N2/2 --
+//   X[k] = P - iQ, X[k'] = P + iQ,  P = B[0] + (-1)^j B[N2/2] + sum_{n2=1..N2/2-1} (B[n2]+B[N2-n2]) cos(2 pi n2 j/N2),
+//                                   Q = sum_{n2=1..N2/2-1} (B[n2]-B[N2-n2]) sin(2 pi n2 j/N2)
+// -- and for j = 0 the pair (k1, k1 + 37*N2/2): sums of the even / odd columns.  A quarter of the MACs of two
+// fft37_step2_bin calls (N2 is a multiple of 4).
+__device__ __forceinline__ void fft37_step2_pair(const cplx* B, const cplx* wN2, int N2, int ldb, int k1, int j,
+                                                 cplx* Xa, cplx* Xb) {
+    const cplx* row = B + k1 * ldb;
+    const int h = N2 >> 1;
+    if (j == 0) {
+        double er = 0.0, ei = 0.0, orr = 0.0, oi = 0.0;
+#pragma unroll 4
+        for (int n2 = 0; n2 < N2; n2 += 2) {
+            const cplx e = row[n2], o = row[n2 + 1];
+            er += e.x; ei += e.y; orr += o.x; oi += o.y;
+        }
+        *Xa = make_double2(er + orr, ei + oi);
+        *Xb = make_double2(er - orr, ei - oi);
+        return;
+    }
+    const cplx b0 = row[0], bh = row[h];
+    const double sg = (j & 1) ? -1.0 : 1.0;
+    double pr = b0.x + sg * bh.x, pi = b0.y + sg * bh.y, qr = 0.0, qi = 0.0;
+    int idx = 0;
+#pragma unroll 5
+    for (int n2 = 1; n2 < h; ++n2) {
+        idx += j;
+        idx = idx >= N2 ? idx - N2 : idx;
+        const cplx u = row[n2], v = row[N2 - n2];
+        const cplx t = wN2[idx];                             // (cos, -sin) of 2 pi n2 j / N2
+        pr = fma(u.x + v.x, t.x, pr); pi = fma(u.y + v.y, t.x, pi);
+        qr = fma(u.x - v.x, t.y, qr); qi = fma(u.y - v.y, t.y, qi);   // q = -Q
+    }
+    *Xa = make_double2(pr - qi, pi + qr);                    // P - iQ = P + i q
+    *Xb = make_double2(pr + qi, pi - qr);
+}
+
 __global__ void k_make_twiddles(cplx* tw, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -809,18 +846,21 @@ __global__ void __launch_bounds__(FK_THREADS) k_fine_chunk(const cplx* __restric
     double es = 0.0;
     for (int i = 0; i < FK_THREADS / 64; ++i) es += sh_e[i];
     const double E = FS_ERR_SCALE_CHUNK * es;
-    // ---- sweep: lane g owns bins 2g, 2g+1 (one pass whenever nfft <= 2*FK_THREADS) ----
-    const int npair = (nfft + 1) >> 1;
+    // ---- sweep: two bins per lane (one pass whenever nfft <= 2*FK_THREADS) ----
+    const int npair = nfft >> 1;                             // nfft = 148*ov is even
     const double sp = sqrt(pstar);
     ChunkRec* r = rec + ((size_t)s * H + w) * nchunk + c;
     float m = 0.0f;
     for (int g0 = 0; g0 < npair; g0 += FK_THREADS) {         // block-uniform trip count
         const int g = g0 + tid;
         const bool act = g < npair;
-        const int k0 = 2 * g, k1 = k0 + 1 < nfft ? k0 + 1 : k0;
+        // lane g owns a mirror pair of bins (any pairing serves the sweep; this one halves the second FFT stage)
+        const int jj = g / 37, kr = g - jj * 37;
+        const int k0 = kr + 37 * jj, k1 = jj == 0 ? kr + 37 * (N2 >> 1) : kr + 37 * (N2 - jj);
         v2f best = {0.0f, 0.0f};
         if (act) {
-            const cplx X0 = fft37_step2_bin(B, wN2, N2, ldb, k0), X1 = fft37_step2_bin(B, wN2, N2, ldb, k1);
+            cplx X0, X1;
+            fft37_step2_pair(B, wN2, N2, ldb, kr, jj, &X0, &X1);
             const cplx t0w = tw_g[k0], t1w = tw_g[k1];       // exp(-2 pi i k/nfft): the recurrence turns by the conjugate
             const v2f wr = {(float)t0w.x, (float)t1w.x}, wi = {(float)-t0w.y, (float)-t1w.y};
             v2f xr = {(float)X0.x, (float)X1.x}, xi = {(float)X0.y, (float)X1.y};
