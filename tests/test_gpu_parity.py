@@ -297,6 +297,42 @@ def test_too_short_capture_is_an_error_not_a_crash(g, setup):
         o.calibrate_stream(raw[0], setup["coef"], setup["ts"], FC)
 
 
+# ---- alternative code paths: every variant must give the oracle's answer ---------------------------------
+def test_front_end_variants_agree(g, setup, monkeypatch):
+    """Register-row front kernel (symmetric / general taps) vs the generic LDS-tap kernel: same calibration."""
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in (30, 31)])
+    sym = setup["coef"]                                        # mirrored taps (synth.fir1, as MATLAB's fir1 returns)
+    gen = o.fir1(46, 200e3 / g.synth.FS)                       # scipy's firwin: symmetric only to the last ulp
+    assert np.array_equal(sym, sym[::-1]) and not np.array_equal(gen, gen[::-1])
+    for coef in (sym, gen):
+        fast = g.calibrate_batch(raw, coef, setup["ts"], FC)
+        det = g.last_batch_details(2)
+        for i in range(2):
+            parity.compare_stream(o.calibrate_stream(raw[i], coef, setup["ts"], FC), fast["table"][i], det, i, fast["pos_info"][i])
+        monkeypatch.setenv("GSMCAL_FRONT_GENERIC", "1")        # read at launch time
+        slow = g.calibrate_batch(raw, coef, setup["ts"], FC)
+        monkeypatch.delenv("GSMCAL_FRONT_GENERIC")
+        assert np.array_equal(fast["table"][:, 6:], slow["table"][:, 6:])           # counts, status
+        np.testing.assert_allclose(fast["table"][:, :6], slow["table"][:, :6], rtol=1e-9, atol=1e-12)
+        assert all(np.array_equal(a, b) for a, b in zip(fast["pos_info"], slow["pos_info"]))
+
+
+@pytest.mark.parametrize("env", [{"GSMCAL_CERT": "0"}, {"GSMCAL_PRESCREEN": "0"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2"}])
+def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
+    """No certificate (every chunk swept), plain all-bin fp64 search, four concurrent lanes: identical tables."""
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in range(40, 48)])
+    ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)                               # read when a context is created
+    other = g.Context(0)
+    try:
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=other)
+    finally:
+        other.close() if hasattr(other, "close") else None
+    assert np.array_equal(ref["table"], out["table"], equal_nan=True)
+    assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
+
+
 # ---- full BASELINE size: size-independent properties ---------------------------------------------------
 def test_full_size_batch_properties(g, setup):
     """64 streams x 1 020 000 samples (BASELINE config 4 on one GPU): (1) every stream's row equals the
