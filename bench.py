@@ -112,17 +112,35 @@ def main():
     dp = gsmcal._lib.c_double_p
     coef_p, ts_p, cf_p = coef.ctypes.data_as(dp), ts.ctypes.data_as(dp), cf.ctypes.data_as(dp)
 
+    # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
+    # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written on its own stream, and
+    # the only wait is before a buffer is written again two steps later (a GPU-side stream wait, the host never
+    # blocks).  The timed region ends with both collectives waited for.
+    tables = [table_t, torch.zeros_like(table_t)] if use_dist else [table_t]
+    gath2 = [gathered, torch.zeros_like(gathered)] if use_dist else None
+    works = [None, None]
+    nstep = [0]
+
     def step():
+        b = (nstep[0] & 1) if use_dist else 0
+        nstep[0] += 1
+        if use_dist and works[b] is not None:
+            works[b].wait()
         rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, coef_p, len(coef), ts_p,
-                                            len(ts), cf_p, C.c_void_p(table_t.data_ptr()),
+                                            len(ts), cf_p, C.c_void_p(tables[b].data_ptr()),
                                             C.c_void_p(pos_t.data_ptr()),
                                             C.c_void_p(r_t.data_ptr()) if r_t is not None else None,
                                             C.c_void_p(rlen_t.data_ptr()))
         ctx.check(rc, "gsmcal_calibrate_batch_dev")
         if use_dist:
-            dist.all_gather_into_tensor(gathered, table_t)   # one RCCL all-gather of the per-dongle ppm table
+            # one RCCL all-gather of the per-dongle ppm table
+            works[b] = dist.all_gather_into_tensor(gath2[b], tables[b], async_op=True)
 
     def fence():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -165,7 +183,7 @@ def main():
         elapsed = float(tt.item())
 
     # ---- results of the last step ----
-    table = table_t.cpu().numpy()
+    table = tables[(nstep[0] - 1) & 1 if use_dist else 0].cpu().numpy()
     det = gsmcal.last_batch_details(min(D, nd), ctx=ctx)
     n_ok = int(np.sum(table[:, 9] == 0))
     total_samples = world * D * N * args.steps
@@ -247,7 +265,8 @@ def main():
         print(json.dumps(out))
     if use_dist:
         if rank == 0 and gathered is not None:
-            assert torch.equal(gathered[:D], table_t), "all-gathered table differs from the local rows"
+            last = (nstep[0] - 1) & 1
+            assert torch.equal(gath2[last][:D], tables[last]), "all-gathered table differs from the local rows"
         dist.destroy_process_group()
 
 

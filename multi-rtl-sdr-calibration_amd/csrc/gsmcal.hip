@@ -67,7 +67,8 @@ struct gsmcal_ctx {
         int seen = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-    } g_calib, g_scan;
+    } g_calib[2], g_scan;           // two calibration graphs: callers that alternate between two output tables keep both
+    unsigned g_calib_lru = 0;
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
@@ -812,7 +813,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->fork) (void)hipEventDestroy(c->fork);
-    for (auto* g : {&c->g_calib, &c->g_scan}) {
+    for (auto* g : {&c->g_calib[0], &c->g_calib[1], &c->g_scan}) {
         if (g->exec) (void)hipGraphExecDestroy(g->exec);
         if (g->graph) (void)hipGraphDestroy(g->graph);
     }
@@ -1326,7 +1327,12 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(join_lanes(c, nl));
     return 0;
     };
-    RET_IF(run_maybe_graph(c, c->g_calib, key, enqueue));
+    int slot = 0;                                            // the slot holding this key, else the one not used last
+    if (c->g_calib[0].key == key) slot = 0;
+    else if (c->g_calib[1].key == key) slot = 1;
+    else slot = 1 - (int)(c->g_calib_lru & 1u);
+    c->g_calib_lru = (unsigned)slot;
+    RET_IF(run_maybe_graph(c, c->g_calib[slot], key, enqueue));
     plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
     c->cur = &c->lanes[0];
     c->last_S = d;
