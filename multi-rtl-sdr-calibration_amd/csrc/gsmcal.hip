@@ -548,7 +548,7 @@ int hits_capacity(long len_dec, int dec_ratio) {
 
 size_t coarse_scan_lds(long nwin, int mv_len, bool speculate = false) {
     return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) +
-           (speculate ? (size_t)MAXH * (32 * sizeof(double) + 2 * sizeof(long)) : 0) + (size_t)(nwin + mv_len + 128) * sizeof(double);
+           (speculate ? (size_t)MAXH * (32 * sizeof(double) + 2 * sizeof(long)) + 144 * sizeof(cplx) : 0) + (size_t)(nwin + mv_len + 128) * sizeof(double);
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,

@@ -94,6 +94,18 @@ __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     return snr_from_power<16>(P);
 }
 
+// the same from 16 samples that are already loaded and DC-corrected (LDS or registers)
+__device__ __forceinline__ double window_snr16_buf(const cplx* b) {
+    cplx x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = b[i];
+    fft16(x);
+    double P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = x[i].x * x[i].x + x[i].y * x[i].y;
+    return snr_from_power<16>(P);
+}
+
 // generic length (2..64) via direct DFT with tw[m] = exp(-2*pi*i*m/L); nothing is stored: the bins
 // around the first max are recomputed (bit-identical) after the scan.
 __device__ __forceinline__ double dft_bin_power(const DecView& v, long start, int fft_len, const cplx* tw, int k) {
@@ -243,7 +255,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
     double* spec_v = (double*)(tw + 64);                  // MAXH x 32: candidate SNRs of the speculative hop walk
     long* spec_nx = (long*)(spec_v + MAXH * 32);          // MAXH x 2: the (nx0, nx1) each row belongs to
-    double* snr_s = a.speculate ? (double*)(spec_nx + MAXH * 2) : spec_v;   // (no table without speculation)
+    cplx* pfb = (cplx*)(spec_nx + MAXH * 2);              // 4 x 36 samples fetched one hop ahead
+    double* snr_s = a.speculate ? (double*)(pfb + 144) : spec_v;   // (none of these without speculation)
     StreamState* st_g = sts + blockIdx.x;
     double mr0 = 0.0, mi0 = 0.0;
     unsigned long long ti0 = 0, tq0 = 0;
@@ -378,13 +391,84 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
             const long limit = (len - (fft_len - 1)) - max_offset;
             long cur = pred + 1;
             int ns = 0;
+            // One hop costs a global round trip (~2 us) plus ~0.8 us of arithmetic.  The samples the NEXT hop can
+            // ask for are known one hop early -- its candidates start at nxt + d - 11 + [0,20] for nxt in {nx0, nx1},
+            // d in {d0, d1}, whatever this hop finds -- so every hop also fetches those 4 x 36 samples (three per
+            // lane) and the following hop takes its windows from LDS.
+            cplx pf0 = make_double2(0.0, 0.0), pf1 = pf0, pf2 = pf0;
+            long pbase0 = 0, pbase1 = 0;                         // nx0 - 11, nx1 - 11 of the hop that prefetched
+            bool have_pf = false, took1 = false;
             while (ns < MAXH - 1) {
                 const long nx0 = cur + d0, nx1 = cur + d1;
                 if (nx0 > limit) break;
+                const long ws = lane < nt ? nx0 - max_offset - 1 + lane : nx1 - max_offset - 1 + (lane - nt);
+                const bool want = lane < nt || (lane < 2 * nt && nx1 <= limit);
+                bool from_lds = false;
+                if (have_pf && fft_len == 16) {
+                    pfb[lane] = pf0; pfb[lane + 64] = pf1;
+                    if (lane + 128 < 144) pfb[lane + 128] = pf2;   // (one wave: its LDS operations stay in order)
+                    const int r = (took1 ? 2 : 0) + (lane < nt ? 0 : 1);
+                    const long off = ws - ((took1 ? pbase1 : pbase0) + (lane < nt ? d0 : d1));
+                    from_lds = want && off >= 0 && off <= 20;
+                    if (!from_lds) { /* direct loads below */ }
+                    else { /* value computed after the next prefetch is issued */ }
+                    // issue the next hop's prefetch before any arithmetic
+                    cplx n0 = make_double2(0.0, 0.0), n1 = n0, n2 = n0;
+                    {
+                        const long b0 = nx0 - 11, b1 = nx1 - 11;
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const int q = lane + 64 * u;
+                            if (q < 144) {
+                                const int rr = q / 36, i = q - rr * 36;
+                                const long gi = ((rr & 2) ? b1 : b0) + ((rr & 1) ? d1 : d0) + i;
+                                const bool ok = gi >= 0 && gi < len && !((rr & 2) && nx1 > limit);
+                                const cplx t = ok ? dv_load(s, gi) : make_double2(0.0, 0.0);
+                                if (u == 0) n0 = t; else if (u == 1) n1 = t; else n2 = t;
+                            }
+                        }
+                    }
+                    double v = -INFINITY;
+                    if (from_lds) v = window_snr16_buf(pfb + r * 36 + (int)off);
+                    else if (want) v = window_snr(s, ws, fft_len, tw);
+                    pf0 = n0; pf1 = n1; pf2 = n2;
+                    pbase0 = nx0 - 11; pbase1 = nx1 - 11;
+                    if (lane < 32) spec_v[ns * 32 + lane] = v;
+                    if (lane == 0) { spec_nx[2 * ns] = nx0; spec_nx[2 * ns + 1] = nx1; }
+                    ++ns;
+                    const unsigned long long hits = __ballot(v - avg_pred > th);
+                    const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
+                    int found;
+                    long nxt;
+                    if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; took1 = false; }
+                    else {
+                        if (nx1 > limit || !h1) break;
+                        found = nt + __ffsll((long long)h1) - 1;
+                        nxt = nx1;
+                        took1 = true;
+                    }
+                    cur = nxt - max_offset + (found >= nt ? found - nt : found);
+                    continue;
+                }
+                // first hop (or a detector length without the 16-point fast path): direct loads; start the pipeline
+                if (fft_len == 16) {
+                    const long b0 = nx0 - 11, b1 = nx1 - 11;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int q = lane + 64 * u;
+                        if (q < 144) {
+                            const int rr = q / 36, i = q - rr * 36;
+                            const long gi = ((rr & 2) ? b1 : b0) + ((rr & 1) ? d1 : d0) + i;
+                            const bool ok = gi >= 0 && gi < len && !((rr & 2) && nx1 > limit);
+                            const cplx t = ok ? dv_load(s, gi) : make_double2(0.0, 0.0);
+                            if (u == 0) pf0 = t; else if (u == 1) pf1 = t; else pf2 = t;
+                        }
+                    }
+                    pbase0 = b0; pbase1 = b1;
+                    have_pf = true;
+                }
                 double v = -INFINITY;
-                if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
-                else if (lane < 2 * nt && nx1 <= limit)
-                    v = window_snr(s, nx1 - max_offset - 1 + (lane - nt), fft_len, tw);
+                if (want) v = window_snr(s, ws, fft_len, tw);
                 if (lane < 32) spec_v[ns * 32 + lane] = v;
                 if (lane == 0) { spec_nx[2 * ns] = nx0; spec_nx[2 * ns + 1] = nx1; }
                 ++ns;
@@ -392,11 +476,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
                 int found;
                 long nxt;
-                if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; }
+                if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; took1 = false; }
                 else {
                     if (nx1 > limit || !h1) break;
                     found = nt + __ffsll((long long)h1) - 1;
                     nxt = nx1;
+                    took1 = true;
                 }
                 cur = nxt - max_offset + (found >= nt ? found - nt : found);
             }
