@@ -1240,12 +1240,30 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             t148[m] = tw_g[D * m];
         }
         __syncthreads();
-        for (int q = tid; q < 148; q += nthr) {
+        // 148 = 4 x 37: Y[k1 + 37 k2] = sum_{n2<4} W148^(n2 (k1+37 k2)) * sum_{n1<37} y[4 n1 + n2] W37^(n1 k1)
+        cplx* A = (cplx*)(pw + 148);                      // [n2][k1], 148 entries
+        for (int o = tid; o < 148; o += nthr) {
+            const int n2 = o / 37, k1 = o - n2 * 37;
             double ar = 0.0, ai = 0.0;
             int idx = 0;
 #pragma unroll 4
-            for (int m = 0; m < 148; ++m) {
-                const cplx v = yd[m], t = t148[idx];
+            for (int n1 = 0; n1 < 37; ++n1) {
+                const cplx v = yd[4 * n1 + n2], t = t148[idx];   // W37^m = W148^(4m)
+                ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
+                ai = fma(v.x, t.y, fma(v.y, t.x, ai));
+                idx += 4 * k1;
+                idx = idx >= 148 ? idx - 148 : idx;
+            }
+            A[o] = make_double2(ar, ai);
+        }
+        __syncthreads();
+        for (int q = tid; q < 148; q += nthr) {
+            const int k1 = q % 37;
+            double ar = 0.0, ai = 0.0;
+            int idx = 0;
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2) {
+                const cplx v = A[n2 * 37 + k1], t = t148[idx];
                 ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
                 ai = fma(v.x, t.y, fma(v.y, t.x, ai));
                 idx += q;
