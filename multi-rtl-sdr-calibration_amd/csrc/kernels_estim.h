@@ -241,14 +241,18 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         P[b] = m * m;                               // P[b]: b < hnl -> bin b; else bin nfft-nb+b
     }
     __syncthreads();
-    if (tid == 0) {
-        // signal: fd([1:3, end-1:end]); noise: fd([4:hnl, end-hnl+1:end-2])   (1-based)
-        double sig = 0.0, noi = 0.0;
-        for (int k = 0; k < 3; ++k) sig += P[k];
-        for (int k = nb - 2; k < nb; ++k) sig += P[k];
-        for (int k = 3; k < hnl; ++k) noi += P[k];
-        for (int k = hnl; k < nb - 2; ++k) noi += P[k];
-        coherent_store(&st->snr_burst[w], 10.0 * log10(sig / noi));
+    if (tid < 64) {
+        // signal: fd([1:3, end-1:end]); noise: fd([4:hnl, end-hnl+1:end-2])   (1-based).  The ~100 noise bins are
+        // added by one wave (a tree instead of a serial loop: the value moves by ~1e-16 relative, it feeds a 5 dB gate)
+        double noi = 0.0;
+        for (int k = 3 + tid; k < nb - 2; k += 64) noi += P[k];
+        for (int off = 32; off > 0; off >>= 1) noi += __shfl_down(noi, off, 64);
+        if (tid == 0) {
+            double sig = 0.0;
+            for (int k = 0; k < 3; ++k) sig += P[k];
+            for (int k = nb - 2; k < nb; ++k) sig += P[k];
+            coherent_store(&st->snr_burst[w], 10.0 * log10(sig / noi));
+        }
     }
     BT_STAMP(4);
 }
@@ -295,13 +299,20 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
         cv[o] = m * m;                      // :53 abs(...).^2
     }
     __syncthreads();
-    if (tid == 0) {
-        int mi = 0;
-        double mx = cv[0];
-        for (int o = 1; o < nshift; ++o)
-            if (cv[o] > mx) { mx = cv[o]; mi = o; }
-        coherent_store(&st->sch_first[w], (double)(st->win_start[w] + 1 + mi));   // sp + max_idx - 1
-        if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
+    if (tid < 64) {                                       // first maximum over the offsets: one wave, then a shuffle tree
+        int mi = 0x7fffffff;
+        double mx = -1.0;
+        for (int o = tid; o < nshift; o += 64)
+            if (cv[o] > mx) { mx = cv[o]; mi = o; }       // (ascending o per lane: strict > keeps the first)
+        for (int off = 32; off > 0; off >>= 1) {
+            const double om = __shfl_down(mx, off, 64);
+            const int oi = __shfl_down(mi, off, 64);
+            if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+        }
+        if (tid == 0) {
+            coherent_store(&st->sch_first[w], (double)(st->win_start[w] + 1 + mi));   // sp + max_idx - 1
+            if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
+        }
     }
 }
 
