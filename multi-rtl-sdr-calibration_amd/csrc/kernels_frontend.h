@@ -543,17 +543,29 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     unsigned short* r_s = (unsigned short*)(smem + gc.off_raw);
     const StreamState* st = sts + s;
     const int level = a.level;
+    // every state field used below, fetched with independent loads up front: the range logic is a chain of small
+    // decisions, and one round trip to L2 per decision (~0.5 us each) was a quarter of this function's time
+    const int pre_nwin = st->n_win;
+    const long pre_n0 = st->n0;
+    const long pre_ws = (!a.tiles && widx >= 0 && widx < MAXH) ? st->win_start[widx] : 0;
+    const double pre_mr = st->mean_re, pre_mi = st->mean_im;
+    int op_type[NLEVELS];
+    double op_param[NLEVELS];
+    long lvl_n[NLEVELS];
+    lvl_n[0] = pre_n0; op_type[0] = OP_NONE; op_param[0] = 0.0;
+#pragma unroll
+    for (int j = 1; j < NLEVELS; ++j) { op_type[j] = st->op[j].type; op_param[j] = st->op[j].param; lvl_n[j] = st->op[j].n; }
     long start, L;
     cplx* dst;
     if (a.tiles) {
-        const long nq = level_len(st, level);
+        const long nq = lvl_n[level];
         start = (long)widx * a.len;
         if (start >= nq) return nullptr;
         L = nq - start < a.len ? nq - start : a.len;
         dst = a.dst + (size_t)s * a.dst_stream_stride + start;
     } else {
-        if (widx >= st->n_win) return nullptr;
-        start = st->win_start[widx];
+        if (widx >= pre_nwin) return nullptr;
+        start = pre_ws;
         L = a.len;
         dst = a.dst + (size_t)s * a.dst_stream_stride + (size_t)widx * a.dst_win_stride;
     }
@@ -562,9 +574,9 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     lo[level] = start;
     hi[level] = start + L - 1;
     for (int j = level; j >= 1; --j) {
-        if (st->op[j].type == OP_LERP) {
-            const double f = st->op[j].param;
-            const long nprev = level_len(st, j - 1);
+        if (op_type[j] == OP_LERP) {
+            const double f = op_param[j];
+            const long nprev = lvl_n[j - 1];
             lo[j - 1] = (long)floor((double)lo[j] * f);
             long h = (long)floor((double)hi[j] * f) + 1;
             hi[j - 1] = h > nprev - 1 ? nprev - 1 : h;
@@ -580,14 +592,14 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     const int tid = threadIdx.x;
     if (a.src_kind == SRC_ARR) {
         const cplx* x = a.arr + (size_t)s * a.arr_stride;
-        const long n0 = st->n0;
+        const long n0 = pre_n0;
         for (int i = tid; i < cnt0; i += NT) {
             const long g = lo0 + i;
             out0[i] = (g >= 0 && g < n0) ? x[g] : make_double2(0.0, 0.0);
         }
     } else {
         const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
-        const long n0 = st->n0;
+        const long n0 = pre_n0;
         const int ntp = a.ntaps;
         const long first = lo0 - (ntp - 1);
         const int span = cnt0 + ntp - 1;
@@ -596,7 +608,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         __syncthreads();
         // raw2iq.m:6-8 on the staged span: (I - mean) + 1i (Q - mean); zero before the stream starts
         // (filter()'s zero initial state) and past its end
-        const double mr = st->mean_re, mi = st->mean_im;
+        const double mr = pre_mr, mi = pre_mi;
         const int off = (int)(first - first_al);
         for (int i = tid; i < span + 8; i += NT) {
             const long g = first + i;
@@ -637,8 +649,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         __syncthreads();
         cplx* o = (j == level && !to_lds) ? dst : other;
         const int cnt = (int)(hi[j] - lo[j] + 1);
-        const int type = st->op[j].type;
-        const double p = st->op[j].param;
+        const int type = op_type[j];
+        const double p = op_param[j];
         const long plo = lo[j - 1], phi_ = hi[j - 1];
         if (type == OP_LERP) {
             for (int i = threadIdx.x; i < cnt; i += NT) {
