@@ -114,6 +114,10 @@ int gsmcal_raw2iq_u8(gsmcal_ctx* ctx, const uint8_t* a, long rows_2n, int d, dou
  * gsm_chn_filter_8x.fda. */
 int gsmcal_chn_filter_8x_4x(gsmcal_ctx* ctx, const double* s, long n, int d,
                             const double* num, int ntaps, double* r);
+/* r = chn_filter_4x(s)                                              chn_filter_4x.m:5-13
+ * Single-rate channel filter at 4x oversampling: s, r: N x D complex.  `num`/`ntaps`: the numerator the
+ * reference loads from gsm_chn_filter_4x.mat (:8-9); NULL/0 = the built-in 30 taps of gsm_chn_filter_4x.fda. */
+int gsmcal_chn_filter_4x(gsmcal_ctx* ctx, const double* s, long n, int d, const double* num, int ntaps, double* r);
 /* r = filter(coef, 1, s) column-wise (gsm_sync_demod.m:110, multi_rtl_sdr_gsm_FCCH_scanner.m:133);
  * keep every `decim`-th row starting with row 1 (decim = 1: all rows; the drivers' r(1:64:end,i)). */
 int gsmcal_filter(gsmcal_ctx* ctx, const double* coef, int ntaps, const double* s, long n, int d,

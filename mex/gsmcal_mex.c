@@ -5,7 +5,7 @@
  * reference would add.  Build one MEX file per function, named like the .m file it shadows, and put
  * the output directory ahead of the reference on the MATLAB path:
  *
- *   for f in raw2iq chn_filter_8x_4x move_fft_snr_runtime_avg specific_fft_snr_fix_avg \
+ *   for f in raw2iq chn_filter_8x_4x chn_filter_4x move_fft_snr_runtime_avg specific_fft_snr_fix_avg \
  *            FCCH_coarse_position FCCH_fine_correction SCH_corr_rate_correction \
  *            carrier_correct_post_SCH total_ppm_calculation; do
  *     mex -R2018a -DGSMCAL_FN_$f -output $f mex/gsmcal_mex.c -Iinclude -Lmulti-rtl-sdr-calibration_amd/lib -lgsmcal
@@ -73,6 +73,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const double* s = cplx_in(prhs[0], &tot);
     plhs[0] = mxCreateDoubleMatrix((n + 1) / 2, d, mxCOMPLEX);
     chk(gsmcal_chn_filter_8x_4x(ctx(), s, (long)n, (int)d, NULL, 0, (double*)mxGetComplexDoubles(plhs[0])), "chn_filter_8x_4x");
+
+#elif defined(GSMCAL_FN_chn_filter_4x)
+    /* r = chn_filter_4x(s)                            chn_filter_4x.m:5 */
+    mwSize n = mxGetM(prhs[0]), d = mxGetN(prhs[0]), tot;
+    const double* s = cplx_in(prhs[0], &tot);
+    plhs[0] = mxCreateDoubleMatrix(n, d, mxCOMPLEX);
+    chk(gsmcal_chn_filter_4x(ctx(), s, (long)n, (int)d, NULL, 0, (double*)mxGetComplexDoubles(plhs[0])), "chn_filter_4x");
 
 #elif defined(GSMCAL_FN_move_fft_snr_runtime_avg)
     /* [hit_flag,hit_idx,hit_avg_snr,hit_snr] = move_fft_snr_runtime_avg(s,mv_len,fft_len,th) */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gsmcal_raw2iq": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p]),
     "gsmcal_raw2iq_u8": (C.c_int, [C.c_void_p, c_u8_p, C.c_long, C.c_int, c_double_p]),
     "gsmcal_chn_filter_8x_4x": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p, C.c_int, c_double_p]),
+    "gsmcal_chn_filter_4x": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, c_double_p, C.c_int, c_double_p]),
     "gsmcal_filter": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p, C.c_long, C.c_int, C.c_int, c_double_p]),
     "gsmcal_move_fft_snr_runtime_avg": (C.c_int, [C.c_void_p, c_double_p, C.c_long, C.c_int, C.c_int, C.c_double,
                                                   c_int_p, c_double_p, c_double_p, c_double_p]),

@@ -7,6 +7,7 @@ sentinel returns (scalar -1.0 / inf, pos_info = [[-1, -1]]) so that tests read l
 
     b = raw2iq(a)                                                   raw2iq.m:5
     r = chn_filter_8x_4x(s)                                         chn_filter_8x_4x.m:5
+    r = chn_filter_4x(s)                                            chn_filter_4x.m:5
     [hit_flag,hit_idx,hit_avg_snr,hit_snr] = move_fft_snr_runtime_avg(s,mv_len,fft_len,th)
     [hit_flag,hit_idx,hit_snr] = specific_fft_snr_fix_avg(s,target_set,fft_len,th,avg_snr)
     [position,snr] = FCCH_coarse_position(s,decimation_ratio)
@@ -168,6 +169,21 @@ def chn_filter_8x_4x(s, num=None, ctx=None):
         num = np.ascontiguousarray(num, dtype=np.float64)
         rc = ctx.lib.gsmcal_chn_filter_8x_4x(ctx.h, _dp(buf), n, d, _dp(num), len(num), _dp(out))
     ctx.check(rc, "chn_filter_8x_4x")
+    return out[0] if squeeze else out.T
+
+
+def chn_filter_4x(s, num=None, ctx=None):
+    """r = chn_filter_4x(s) -- chn_filter_4x.m:5-13 (30 built-in taps of gsm_chn_filter_4x.fda unless `num` is given)."""
+    ctx = ctx or default_context()
+    squeeze = np.asarray(s).ndim == 1
+    buf, n, d = _cplx_in(s)
+    out = np.empty((d, n), dtype=np.complex128)
+    if num is None:
+        rc = ctx.lib.gsmcal_chn_filter_4x(ctx.h, _dp(buf), n, d, None, 0, _dp(out))
+    else:
+        num = np.ascontiguousarray(num, dtype=np.float64)
+        rc = ctx.lib.gsmcal_chn_filter_4x(ctx.h, _dp(buf), n, d, _dp(num), len(num), _dp(out))
+    ctx.check(rc, "chn_filter_4x")
     return out[0] if squeeze else out.T
 
 

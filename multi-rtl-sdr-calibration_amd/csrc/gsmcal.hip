@@ -949,6 +949,11 @@ int gsmcal_chn_filter_8x_4x(gsmcal_ctx* c, const double* s, long n, int d, const
     return gsmcal_filter(c, num, ntaps, s, n, d, 2, r);   // chn_filter_8x_4x.m:13,15
 }
 
+int gsmcal_chn_filter_4x(gsmcal_ctx* c, const double* s, long n, int d, const double* num, int ntaps, double* r) {
+    if (!num || ntaps <= 0) { num = GSM_CHN_FILTER_4X_NUM; ntaps = 30; }
+    return gsmcal_filter(c, num, ntaps, s, n, d, 1, r);   // chn_filter_4x.m:13: no decimation
+}
+
 // ---- a3..a5 coarse detector -----------------------------------------------------------------------
 static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, StreamState* out) {
     HIPCHK(c, hipSetDevice(c->device));

@@ -107,6 +107,12 @@ def chn_filter_8x_4x(s, num):
     return r[0::2]
 
 
+def chn_filter_4x(s, num):
+    """r = chn_filter_4x(s): chn_filter_4x.m:13 filter(Num,1,s), no decimation.  `num` is the 30-tap numerator the
+    reference loads from gsm_chn_filter_4x.mat (:8-9)."""
+    return matlab_filter(num, s)
+
+
 # ------------------------------------------------------------------------------------------------
 # shared: per-window SNR of move_fft_snr_runtime_avg.m:18-27 / specific_fft_snr_fix_avg.m:11-20
 # ------------------------------------------------------------------------------------------------

@@ -67,6 +67,16 @@ def test_chn_filter_8x_4x_matches_oracle(g, setup):
     assert np.max(np.abs(g.chn_filter_8x_4x(s, setup["num"]) - want)) < 1e-13
 
 
+def test_chn_filter_4x_matches_oracle(g, setup):
+    # chn_filter_4x.m:13: filter(Num,1,s) with the 30 taps of gsm_chn_filter_4x.fda, every row kept
+    num4 = o.load_num(os.path.join(HERE, "golden", "gsm_chn_filter_4x_num.txt"))
+    rng = np.random.default_rng(4)
+    s = rng.standard_normal((5001, 2)) + 1j * rng.standard_normal((5001, 2))
+    want = o.chn_filter_4x(s, num4)
+    assert np.max(np.abs(g.chn_filter_4x(s) - want)) < 1e-13          # built-in taps == the .fda numerator
+    assert np.max(np.abs(g.chn_filter_4x(s[:, 0], num4) - want[:, 0])) < 1e-13
+
+
 def test_driver_front_end_filter_and_decimation(g, setup):
     # gsm_sync_demod.m:107,110,117: r = raw2iq(s); r = filter(coef,1,r); r(1:64:end,i)
     raw = np.stack([g.synth.make_stream(dongle=d, num_frames=8)[0] for d in (0, 1)])

@@ -62,6 +62,15 @@ def test_filter_is_causal_zero_state_and_decimator_keeps_odd_rows():
     r = o.chn_filter_8x_4x(x, num)
     assert len(r) == 50 and np.allclose(r.real[:30], num[0::2])            # r(1:2:end)
 
+def test_chn_filter_4x_is_a_plain_causal_filter():
+    # chn_filter_4x.m:13: r = filter(coef,1,s), all rows kept, zero initial state
+    num4 = o.load_num(os.path.join(GOLD, "gsm_chn_filter_4x_num.txt"))
+    x = np.zeros(64, dtype=np.complex128)
+    x[3] = 1.0 + 2.0j
+    r = o.chn_filter_4x(x, num4)
+    assert r.shape == x.shape and np.all(r[:3] == 0)
+    assert np.allclose(r[3:33], (1.0 + 2.0j) * num4, rtol=0, atol=1e-18)
+
 
 def test_toeplitz_slice_equals_sliding_windows():
     # FCCH_fine_correction.m:48-49: toeplitz(...)(len:end, end:-1:1) column k == s(sp+k-1 : sp+k-1+fft_len-1)
