@@ -872,7 +872,8 @@ struct ChunkRec {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_fine_chunk: grid (nchunk, H, S), block FK_THREADS.  Blocks of chunks the certificate closed exit at once.
+// k_fine_chunk: persistent workgroups (3 per CU, block FK_THREADS) over the list of open (window, chunk) items that
+// k_fine_cert (or k_fine_openall) wrote.
 // LDS: xs[nfft+64] | B[37][N2+1] | w37 (40) | wN2 | d[64] (float2).
 // ------------------------------------------------------------------------------------------------
 #define FK_THREADS 640
@@ -1060,7 +1061,15 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
         }
     }
     const int nopen = fc.nch;
-    const ChunkRec* r = rec + ((size_t)s * H + w) * nchunk;
+    // the open chunks' records (256 B each) come into LDS with one round of coalesced loads; the window's place is free
+    ChunkRec* r = (ChunkRec*)smem;
+    {
+        const uint4* src = (const uint4*)(rec + ((size_t)s * H + w) * nchunk);
+        uint4* dst = (uint4*)r;
+        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += 256) dst[i] = src[i];
+    }
+    if (tid == 0) { n_items = 0; n_over = 0; }
+    __syncthreads();
     // the bar a pair must reach: the certificate's exact maximum, or the best guaranteed amplitude of any open chunk
     double L = fc.p > 0.0 ? sqrt(fc.p) : 0.0;
     for (int c = 0; c < nopen; ++c) {
@@ -1068,8 +1077,6 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
         if (v > L) L = v;
     }
     L *= 1.0 - 1e-9;
-    if (tid == 0) { n_items = 0; n_over = 0; }
-    __syncthreads();
     for (int i = tid; i < nopen * FK_CAP; i += 256) {     // listed candidates of all open chunks
         const int c = i / FK_CAP, q = i - c * FK_CAP;
         const int cnt = r[c].count;
