@@ -625,17 +625,34 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
             double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
             cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
-            int p = i0 + 3;
-            for (int k = ntp - 1; k >= 0; --k) {
-                const double c = c_s[k];
-                ar0 = fma(c, w0.x, ar0); ai0 = fma(c, w0.y, ai0);
-                ar1 = fma(c, w1.x, ar1); ai1 = fma(c, w1.y, ai1);
-                ar2 = fma(c, w2.x, ar2); ai2 = fma(c, w2.y, ai2);
-                ar3 = fma(c, w3.x, ar3); ai3 = fma(c, w3.y, ai3);
+#define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
+                ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);         \
+                ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
+                ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
+                ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
+            // four taps per trip: the next four samples are one aligned, contiguous 64-byte group (i0 is a multiple
+            // of 4), fetched together, and the sliding window needs no register shuffling.  Every accumulator still
+            // takes its taps in the same order (oldest first), so the sums are bit-identical to the one-tap loop.
+            int t = 0;
+            for (; t + 4 <= ntp; t += 4) {
+                const cplx* nx = xs + xs_pad(i0 + t + 4);
+                const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
+                const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];
+                GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
+                GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
+                GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
+                GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
+                w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
+            }
+            int p = i0 + t + 3;
+            for (; t < ntp; ++t) {
+                const double c = c_s[ntp - 1 - t];
+                GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
                 w0 = w1; w1 = w2; w2 = w3;
                 ++p;
                 w3 = xs[xs_pad(p)];
             }
+#undef GSMCAL_FIR_TAP
             out0[i0] = make_double2(ar0, ai0);
             if (i0 + 1 < cnt0) out0[i0 + 1] = make_double2(ar1, ai1);
             if (i0 + 2 < cnt0) out0[i0 + 2] = make_double2(ar2, ai2);
