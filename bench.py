@@ -175,6 +175,24 @@ def main():
             torch.cuda.synchronize(dev)
             store.update(ctx.profile_get())
             ctx.profile_enable(False)
+    # BASELINE config 2 (gsm_sync_demod.m on 2 dongle streams): the same call on the first two streams, for the record
+    cfg2 = None
+    if rank == 0 and D >= 2 and args.mode == "table" and not use_dist:
+        def two():
+            ctx.check(lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), 2, N, coef_p, len(coef), ts_p, len(ts),
+                                                     cf_p, C.c_void_p(table_t.data_ptr()), C.c_void_p(pos_t.data_ptr()), None,
+                                                     C.c_void_p(rlen_t.data_ptr())), "gsmcal_calibrate_batch_dev")
+        for _ in range(3):
+            two()
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        for _ in range(args.steps):
+            two()
+        torch.cuda.synchronize(dev)
+        t2 = (time.perf_counter() - c0) / args.steps
+        cfg2 = {"streams": 2, "ms_per_call": round(1e3 * t2, 4), "Msample_per_s": round(2 * N / t2 / 1e6, 1)}
+        step()                                  # restore the full batch's outputs and lane bookkeeping
+        torch.cuda.synchronize(dev)
     if use_dist:
         fence()
     if use_dist:
@@ -203,6 +221,8 @@ def main():
                    "collective": "all_gather(table) over RCCL" if use_dist else "none",
                    "streams_calibrated_ok": n_ok},
     }
+    if cfg2:
+        out["baseline_config2_two_streams"] = cfg2
 
     if rank == 0:
         # ---- roofline (HIP events on the launch streams, inside the timed region) ----
