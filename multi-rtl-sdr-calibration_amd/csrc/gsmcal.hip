@@ -74,7 +74,7 @@ struct gsmcal_ctx {
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
-    bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, the prescreen sweeps every window in full
+    bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
     bool capturing = false;
     // shared workspace
     DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;

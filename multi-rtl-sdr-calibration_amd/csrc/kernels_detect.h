@@ -1,14 +1,17 @@
-// kernels_detect.h -- FCCH coarse detector and the sliding-DFT peak search.
+// kernels_detect.h -- FCCH coarse detector and the fine (sliding-DFT) peak search.
 //
-//   k_coarse      FCCH_coarse_position.m:5-94 with move_fft_snr_runtime_avg.m:5-50 and
-//                 specific_fft_snr_fix_avg.m:5-34 inside: one workgroup per stream; all sliding
-//                 window SNRs in parallel, then the reference's serial moving-average recurrence
-//                 (bit-for-bit the same update order) and the hop loop, all on the device.
-//   k_fft_burst   1184-point spectra (37 x 32 Cooley-Tukey in LDS): burst spectrum argmax of
-//                 FCCH_fine_correction.m:148-150 / carrier_correct_post_SCH.m:63-65, and the starting
-//                 spectrum of the fine search
-//   k_fine_search FCCH_fine_correction.m:48-52: max over 1025 window starts of max_k |FFT_1184|^2,
-//                 as an exact sliding DFT (one bin per lane, fp64 state)
+//   k_coarse_snr / k_coarse_scan
+//                 FCCH_coarse_position.m:5-94 with move_fft_snr_runtime_avg.m:5-50 and
+//                 specific_fft_snr_fix_avg.m:5-34 inside: all sliding-window SNRs in parallel, then one
+//                 workgroup per stream replays the reference's serial moving-average recurrence (bit for
+//                 bit the same update order) and walks the hops, all on the device.
+//   k_fine_cert / k_fine_chunk / k_fine_verify (body)
+//                 FCCH_fine_correction.m:48-52: max over 1025 window starts of max_k |FFT_1184|^2 --
+//                 exact certificate on the tone's bins, packed-fp32 sweep of the chunks it leaves open,
+//                 exact fp64 on what survives (see the comment block above FS_CHUNK).
+//   k_fft_burst   1184-point spectra (37 x 32 Cooley-Tukey in LDS); fft37_* are its building blocks, shared
+//                 with k_fine_chunk and k_burst_tone.
+//   k_fine_search the plain all-bin fp64 sliding DFT (GSMCAL_PRESCREEN=0): cross-check of the scheme above.
 #pragma once
 #include "state.h"
 #include "kernels_frontend.h"
@@ -1171,7 +1174,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
 //   3. shift t is "certified" when R(t) (plus the rounding margin of the fp32 group sums) < P*.
 // The certified shifts form a range [a, b] around t*; what is left for the all-bin search is the prefix
 // [0, a) -- and, rarely, a suffix, in which case everything is searched.  Output: (P*, t*, k*), a, b and
-// nch = number of leading 64-shift chunks k_fine_prescreen still has to sweep (0: the window is settled).
+// nch = number of leading 64-shift chunks k_fine_chunk still has to sweep (0: the window is settled).
 // Anchors by a two-level regrouping of the DFT sum (exact algebra, fp64): with B = gcd(64, nfft),
 //   S_k(m) = sum_{b<B} x[B*m+b] W^(k*b),   X_k(64c) = sum_{a<nfft/B} W^(k*B*a) * S_k(64c/B + a),   W = exp(-2 pi i/nfft)
 // i.e. nfft/B + (wlen/B)*B/nchunk MACs per anchor instead of nfft.

@@ -3,8 +3,10 @@
 //   k_burst_tone  gather + spectrum argmax + tone-frequency estimator of FCCH_fine_correction.m:148-155
 //                 (+ SNR gate :185-189) and carrier_correct_post_SCH.m:63-72, one workgroup per burst
 //   k_window_sch  gather + SCH_corr_rate_correction.m:50-55: |sch_ts' * window|^2 for the 89 offsets
-//   k_*_setup / k_*_decide   the integer / ppm logic of the reference functions, one thread per
-//                 stream, writing the next stage's window list into StreamState
+//   d_*_setup / d_*_decide   the integer / ppm logic of the reference functions, one thread per stream on an LDS
+//                 copy of its state, writing the next stage's window list; run by stream_tail in the last
+//                 per-window workgroup of the stream (or by k_step where a stage has no per-window kernel)
+//   k_fine_verify the global wrapper of fine_verify_body (kernels_detect.h) + FINE_DECIDE tail
 #pragma once
 #include "state.h"
 #include "kernels_frontend.h"

@@ -5,6 +5,8 @@
 //   k_raw2iq        raw2iq.m:6-8    materialise c - mean as complex double
 //   k_fir_decim_raw gsm_sync_demod.m:107,110,117 / ..FCCH_scanner.m:132-135 fused: only the kept
 //                   rows r(1:decim:end) of filter(coef,1,raw2iq(s)) are computed
+//   k_front_fused   batch paths: ONE pass over the raw bytes -> exact byte sums + FIR of the RAW samples at the
+//   k_front_fast<NT,SYM>  kept rows (any geometry / 47- or 31-tap decimate-by-64 with rows held in registers)
 //   k_fir_arr       filter(coef,1,s) (+ r(1:decim:end,:)) on a complex array (chn_filter_8x_4x.m:13-15)
 //   k_gather        evaluates a window (or every tile) of a stream at any level of the lazy chain
 //                   (state.h) through LDS: raw -> FIR -> lerp -> mix -> lerp -> mix
