@@ -174,6 +174,33 @@ def test_chain_function_by_function(g, setup, dongle):
     parity.assert_ppm(tot[1], o.total_ppm_calculation([o_cp1, o_cp2]), "total carrier ppm")
 
 
+@pytest.mark.parametrize("ov", [4, 2])
+def test_chain_at_other_oversampling_ratios(g, setup, ov):
+    """The per-function API takes the oversampling ratio as an argument (every .m file does): 4x and 2x streams
+    exercise the general-geometry paths (592- / 296-point spectra, 8 / 4 chunks, other FFT factorisations)."""
+    raw, r8 = _coarse_input(g, setup, 3)
+    step = 8 // ov
+    r = np.ascontiguousarray(r8[0::step])
+    ts = np.ascontiguousarray(setup["ts"][0::step])
+    o_pos, _ = o.FCCH_coarse_position(r[0::8 * ov], 8)
+    pos, _ = g.FCCH_coarse_position(r[0::8 * ov], 8)
+    parity.assert_positions(pos, o_pos, "coarse position")
+    o_fp, o_r1, o_sp1, o_cp1 = o.FCCH_fine_correction(r, o_pos, ov, FC)
+    fp, r1, sp1, cp1 = g.FCCH_fine_correction(r, pos, ov, FC)
+    parity.assert_positions(fp, o_fp, "FCCH_pos")
+    parity.assert_ppm(sp1, o_sp1, "sampling_ppm(1)")
+    parity.assert_ppm(cp1, o_cp1, "carrier_ppm(1)")
+    if isinstance(o_r1, np.ndarray):
+        stream_close(r1, o_r1)
+        o_pi, o_r2, o_sp2 = o.SCH_corr_rate_correction(o_r1, o_fp, ts, ov)
+        pi, r2, sp2 = g.SCH_corr_rate_correction(r1, fp, ts, ov)
+        parity.assert_positions(pi, o_pi if not np.all(o_pi == -1) else np.array([[-1.0, -1.0]]), "pos_info")
+        parity.assert_ppm(sp2, o_sp2, "sampling_ppm(2)")
+        o_r3, o_cp2 = o.carrier_correct_post_SCH(o_r2, o_pi, ov, FC)
+        r3, cp2 = g.carrier_correct_post_SCH(r2, pi, ov, FC)
+        parity.assert_ppm(cp2, o_cp2, "carrier_ppm(2)")
+
+
 def test_fine_correction_sentinels(g, setup):
     _, r = _coarse_input(g, setup, 0)
     # fewer than 5 coarse hits (FCCH_fine_correction.m:12-15)
