@@ -370,6 +370,28 @@ def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
 
 
+def test_large_batches_take_the_throughput_paths(g, setup):
+    """More than 512 units: no speculative hop walk, SNR table from its own kernel, four workgroups per CU in the
+    coarse scan, two lanes in the calibration chain -- same answers."""
+    distinct = [g.synth.make_stream(dongle=60 + i, num_frames=61)[0] for i in range(4)]
+    raw = np.stack([distinct[i % 4] for i in range(520)])
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    det = g.last_batch_details(4)
+    for i in range(4):
+        orc = o.calibrate_stream(distinct[i], setup["coef"], setup["ts"], FC)
+        parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+    for i in range(4, 520):                                  # every copy of a stream gives the same row
+        assert np.array_equal(out["table"][i], out["table"][i % 4], equal_nan=True)
+    caps = [g.synth.make_stream(dongle=70, arfcn=i, num_frames=40, bcch=(i != 2))[0] for i in range(3)]
+    raw = np.stack([caps[i % 3] for i in range(600)])
+    sc = g.fcch_scan_batch(raw, setup["coef30"])
+    for i in range(3):
+        live = o.scan_capture(caps[i], setup["coef30"])
+        assert live["num_hit"] == sc["num_hit"][i] and abs(live["snr"] - sc["snr"][i]) < parity.SNR_ATOL
+    assert np.array_equal(sc["num_hit"][3:], np.tile(sc["num_hit"][:3], 200)[3:])
+    assert np.array_equal(sc["snr"][3:], np.tile(sc["snr"][:3], 200)[3:])
+
+
 # ---- full BASELINE size: size-independent properties ---------------------------------------------------
 def test_full_size_batch_properties(g, setup):
     """64 streams x 1 020 000 samples (BASELINE config 4 on one GPU): (1) every stream's row equals the
