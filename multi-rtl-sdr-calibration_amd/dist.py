@@ -50,3 +50,39 @@ def sampling_phase_difference(pos_info_a, pos_info_b):
     b = np.atleast_2d(np.asarray(pos_info_b, dtype=np.float64))
     n = min(len(a), len(b))
     return b[:n, 0] - a[:n, 0]
+
+
+def scan_frequency_plan(start_freq, end_freq, freq_step, num_dongle):
+    """multi_rtl_sdr_gsm_FCCH_scanner.m:60-65: the ARFCN grid split across dongles.
+
+    freq_orig = start:step:end, padded at the end (continuing the grid) to a multiple of num_dongle, then
+    vec2mat(freq, num_freq_per_sub_band): row i = the consecutive sub-band dongle i sweeps.  Returns
+    (freq[num_dongle, num_freq_per_sub_band], num_pad).  Unit index of (dongle i, point j) in the gathered
+    scan table: i*num_freq_per_sub_band + j (the order of s_all / snr / num_hit, :69,:163-186)."""
+    n = int(np.floor((end_freq - start_freq) / freq_step + 1e-9)) + 1           # length(start:step:end)
+    freq_orig = start_freq + freq_step * np.arange(n, dtype=np.float64)
+    per = -(-n // num_dongle)                                                   # ceil
+    num_pad = per * num_dongle - n
+    freq = np.concatenate([freq_orig, freq_orig[-1] + freq_step * np.arange(1, num_pad + 1)])
+    return freq.reshape(num_dongle, per), num_pad
+
+
+def scan_record(snr, num_hit, start_freq, end_freq, freq_step, num_dongle, gain, num_samples, sampling_rate, coef):
+    """The fields the scanner saves (multi_rtl_sdr_gsm_FCCH_scanner.m:206-207), from the gathered scan table."""
+    freq, _ = scan_frequency_plan(start_freq, end_freq, freq_step, num_dongle)
+    snr = np.asarray(snr, dtype=np.float64).ravel()
+    num_hit = np.asarray(num_hit, dtype=np.float64).ravel()
+    if snr.size != freq.size or num_hit.size != freq.size:
+        raise ValueError("scan table does not match the frequency plan")
+    return {"snr": snr, "num_hit": num_hit, "start_freq": start_freq, "end_freq": end_freq, "freq_step": freq_step,
+            "observe_time": num_samples / sampling_rate, "gain": gain, "sampling_rate": sampling_rate,
+            "coef": np.asarray(coef, dtype=np.float64), "freq": freq,
+            "filename": "FCCH_scan_%s_%s_gain%s_%sdongles.mat" % (_num2str(start_freq), _num2str(end_freq),
+                                                                  _num2str(gain), _num2str(num_dongle))}
+
+
+def _num2str(v):
+    """MATLAB num2str for the integers / short decimals the scanner prints ('%.Ng' with N = digits + 4)."""
+    if float(v) == int(v):
+        return str(int(v))
+    return ("%11.5g" % v).strip()

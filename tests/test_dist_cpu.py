@@ -65,3 +65,17 @@ def test_sampling_phase_difference():
     a = np.array([[100.0, 0], [10100.0, 1], [20100.0, 2]])
     b = np.array([[103.0, 0], [10103.0, 1]])
     assert np.array_equal(gd.sampling_phase_difference(a, b), [3.0, 3.0])
+
+
+def test_scan_frequency_plan_matches_the_scanner_grid():
+    from gsmcal import dist as gd
+    # multi_rtl_sdr_gsm_FCCH_scanner.m:28-34,60-65: 935:0.2:960 MHz = 126 points; 2 dongles -> 63 each, no padding
+    freq, pad = gd.scan_frequency_plan(935e6, 960e6, 0.2e6, 2)
+    assert freq.shape == (2, 63) and pad == 0
+    assert freq[0, 0] == 935e6 and abs(freq[1, -1] - 960e6) < 1e-3 and abs(freq[1, 0] - (935e6 + 63 * 0.2e6)) < 1e-3
+    # 4 dongles: ceil(126/4) = 32 per sub-band, 2 padded points continuing the grid past end_freq
+    freq, pad = gd.scan_frequency_plan(935e6, 960e6, 0.2e6, 4)
+    assert freq.shape == (4, 32) and pad == 2 and abs(freq[3, -1] - (960e6 + 2 * 0.2e6)) < 1e-3
+    rec = gd.scan_record(np.zeros(128), np.zeros(128), 935e6, 960e6, 0.2e6, 4, 0, 640000, 8 * 1625e3 / 6, np.ones(31))
+    assert rec["filename"] == "FCCH_scan_935000000_960000000_gain0_4dongles.mat"
+    assert abs(rec["observe_time"] - 640000 / (8 * 1625e3 / 6)) < 1e-15 and rec["freq"].shape == (4, 32)
