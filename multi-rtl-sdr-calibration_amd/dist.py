@@ -52,6 +52,36 @@ def sampling_phase_difference(pos_info_a, pos_info_b):
     return b[:n, 0] - a[:n, 0]
 
 
+def _matlab_round(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def burst_map(pos_info, oversampling_ratio=8):
+    """gsm_sync_demod.m:130-134: per GSM frame index (1-based, round(start / 10000) at 8x) the burst type found in
+    slot 0 -- 0 FCCH, 1 SCH, 2 BCCH, NaN nothing; later types overwrite earlier ones as in the reference."""
+    p = np.atleast_2d(np.asarray(pos_info, dtype=np.float64))
+    if p.size == 0 or np.all(p == -1):
+        return np.empty(0)
+    per_frame = 1250.0 * oversampling_ratio
+    idx = _matlab_round(p[:, 0] / per_frame).astype(np.int64)
+    a = np.full(int(idx.max()), np.nan)
+    for kind in (0, 1, 2):
+        sel = idx[p[:, 1] == kind]
+        a[sel[sel >= 1] - 1] = kind
+    return a
+
+
+def sampling_phase_frames(pos_info_a, pos_info_b, oversampling_ratio=8):
+    """x axis of the reference's phase-difference plot (gsm_sync_demod.m:151-155): frame index of each compared burst,
+    taken from the dongle with fewer rows."""
+    a = np.atleast_2d(np.asarray(pos_info_a, dtype=np.float64))
+    b = np.atleast_2d(np.asarray(pos_info_b, dtype=np.float64))
+    short = a if len(a) <= len(b) else b
+    n = min(len(a), len(b))
+    return _matlab_round(short[:n, 0] / (1250.0 * oversampling_ratio))
+
+
 def scan_frequency_plan(start_freq, end_freq, freq_step, num_dongle):
     """multi_rtl_sdr_gsm_FCCH_scanner.m:60-65: the ARFCN grid split across dongles.
 

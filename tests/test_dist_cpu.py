@@ -79,3 +79,16 @@ def test_scan_frequency_plan_matches_the_scanner_grid():
     rec = gd.scan_record(np.zeros(128), np.zeros(128), 935e6, 960e6, 0.2e6, 4, 0, 640000, 8 * 1625e3 / 6, np.ones(31))
     assert rec["filename"] == "FCCH_scan_935000000_960000000_gain0_4dongles.mat"
     assert abs(rec["observe_time"] - 640000 / (8 * 1625e3 / 6)) < 1e-15 and rec["freq"].shape == (4, 32)
+
+
+def test_burst_map_and_phase_frames():
+    from gsmcal import dist as gd
+    # FCCH at frame 1, SCH at frame 2, BCCH at frames 3-4 (8x: 10 000 samples per frame)
+    pi = np.array([[10010.0, 0], [20010.0, 1], [30010.0, 2], [40010.0, 2]])
+    m = gd.burst_map(pi, 8)
+    assert len(m) == 4 and list(m) == [0.0, 1.0, 2.0, 2.0]
+    pi2 = np.array([[60010.0, 0]])
+    m2 = gd.burst_map(pi2, 8)
+    assert len(m2) == 6 and np.all(np.isnan(m2[:5])) and m2[5] == 0
+    assert gd.burst_map(np.array([[-1.0, -1.0]])).size == 0
+    assert list(gd.sampling_phase_frames(pi, pi[:2] + [3.0, 0], 8)) == [1.0, 2.0]
