@@ -50,18 +50,14 @@ __device__ __forceinline__ void fft16(cplx* x) {
 // around it vs the rest, in dB.  L is a compile-time constant so P stays in registers.
 template <int L>
 __device__ __forceinline__ double snr_from_power(const double (&P)[L]) {
-    int mi = 0;
-    double mx = P[0];
-#pragma unroll
-    for (int k = 1; k < L; ++k)
-        if (P[k] > mx) { mx = P[k]; mi = k; }       // first max
+    // first max (strict >) and its two circular neighbours, carried along in one pass
     double pm = P[L - 1], pc = P[0], pp = P[1 % L];
 #pragma unroll
     for (int k = 1; k < L; ++k) {
-        const bool h = (k == mi);
+        const bool h = P[k] > pc;
         pm = h ? P[k - 1] : pm;
-        pc = h ? P[k] : pc;
         pp = h ? P[(k + 1) % L] : pp;
+        pc = h ? P[k] : pc;
     }
     double sig = pm + pc;
     sig = sig + pp;
@@ -259,7 +255,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     double* spec_v = (double*)(tw + 64);                  // MAXH x 32: candidate SNRs of the speculative hop walk
     long* spec_nx = (long*)(spec_v + MAXH * 32);          // MAXH x 2: the (nx0, nx1) each row belongs to
     cplx* pfb = (cplx*)(spec_nx + MAXH * 2);              // 4 x 36 samples fetched one hop ahead
-    double* snr_s = a.speculate ? (double*)(pfb + 144) : spec_v;   // (none of these without speculation)
+    constexpr bool SPEC = WAVES < 4;                      // the large-batch build carries no speculation code at all
+    double* snr_s = (SPEC && a.speculate) ? (double*)(pfb + 144) : spec_v;   // (none of these without speculation)
     StreamState* st_g = sts + blockIdx.x;
     double mr0 = 0.0, mi0 = 0.0;
     unsigned long long ti0 = 0, tq0 = 0;
@@ -320,7 +317,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     // windows, sums the mv_len entries its first window sees directly and slides from there; the sums differ
     // from the reference's serially rounded ones by ~1e-12, so the predicted first hit is the exact one unless
     // a window sits within that of the threshold.  Only the SPECULATION below depends on it, never a result.
-    if (!bad && a.mode == 0 && a.speculate) {
+    if (SPEC && !bad && a.mode == 0 && a.speculate) {
         const int per = (int)((g.nwin + 255) / 256);
         const int j0 = tid * per, j1 = j0 + per < (int)g.nwin ? j0 + per : (int)g.nwin;
         if (j0 < j1) {
@@ -377,7 +374,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 }
             }
         }
-        else if (tid < 128 && a.mode == 0 && sh_pred != 0x7fffffff) {
+        else if (SPEC && tid < 128 && a.mode == 0 && sh_pred != 0x7fffffff) {
             // ---- wave 1, while wave 0 replays the exact sums: walk the hops of FCCH_coarse_position.m:32-86 from the
             // PREDICTED hit and keep every candidate SNR it evaluates.  The SNRs are exact (they do not depend on
             // the prediction); the real walk below takes them from the table whenever it asks for the same windows.
@@ -529,7 +526,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                         if (nx0 > limit) break;                              // :49
                         double v = -INFINITY;
                         const int hs = n - 1;                                // this hop's row of the speculative walk
-                        if (hs < sh_nspec && spec_nx[2 * hs] == nx0 && spec_nx[2 * hs + 1] == nx1) {
+                        if (SPEC && hs < sh_nspec && spec_nx[2 * hs] == nx0 && spec_nx[2 * hs + 1] == nx1) {
                             if (lane < 2 * nt) v = spec_v[hs * 32 + lane];   // same windows: same SNRs, already computed
                         } else if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
                         else if (lane < 2 * nt && nx1 <= limit)
