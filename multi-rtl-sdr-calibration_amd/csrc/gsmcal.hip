@@ -525,7 +525,7 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
     if ((ntaps == 47 || ntaps == 31) && decim == 64 && ((uintptr_t)d_raw & 15) == 0 && ((2 * n) & 15) == 0 &&
         !getenv("GSMCAL_FRONT_GENERIC")) {
         // the production geometries (fir1(46) / fir1(30), 8x oversampling, aligned captures): rows in registers
-        const size_t flds = ((size_t)lds_pad_host(8 * 2048) * 2 + 15) & ~(size_t)15;
+        const size_t flds = (size_t)2048 * 16;              // swizzled, unpadded: five workgroups per CU
         c->cur->npartial = (int)nblk * 4;                  // this kernel writes one partial per wave
 #define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef, nd, d_out, out_stride)
         if (ntaps == 47) { if (sym) FRONT_FAST(k_front_fast47_sym); else FRONT_FAST(k_front_fast47); }

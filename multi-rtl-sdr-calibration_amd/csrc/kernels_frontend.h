@@ -348,9 +348,13 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
 // 64j-NT+1 .. 64j) and the rows tile the stream, so the byte sums of the rows are the stream's sums (the last
 // block adds the <= 48 samples past its last row).  Samples outside [0, n) are staged as zeros: zero initial
 // state of filter(), and nothing for the sums.
-// grid (ceil(nd/256), S), block 256.  LDS: 2048 chunks of 8 samples, rows padded to 144 bytes; partial sums: 4 per block.
+// grid (ceil(nd/256), S), block 256.  LDS: 2048 chunks of 8 samples, swizzled (32 KB); partial sums: 4 per block.
 // ------------------------------------------------------------------------------------------------
 #define FFAST_CHUNKS (2048 + 6)
+// LDS slot (in 16-byte chunks) of chunk i of row r: an XOR swizzle instead of padding.  Any 16 consecutive lanes --
+// of the staging stores (two rows, eight chunks each) and of the row loads (16 rows, one chunk index) -- touch
+// 16 different 16-byte bank groups, and the 2048 chunks take exactly 32 KB: five workgroups per CU instead of four.
+__device__ __forceinline__ int ffast_slot(int c) { return (c & ~7) | ((c & 7) ^ ((c >> 4) & 7)); }
 __device__ __forceinline__ uint4 ffast_chunk(const unsigned short* __restrict__ base, long g0, long n) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);                   // 8 samples from g0, zeros outside [0, n)
     if (g0 >= 0 && g0 + 8 <= n) {
@@ -388,14 +392,13 @@ __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = ffast_chunk(base, first_al + 8L * (512 * wave + lane + 64 * u), n);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) *(uint4*)(r_s + lds_pad(8 * (512 * wave + lane + 64 * u))) = v[u];
+        for (int u = 0; u < 8; ++u) *(uint4*)(r_s + 8 * ffast_slot(512 * wave + lane + 64 * u)) = v[u];
     }
     unsigned w[32];                                         // this lane's row
     {
-        const uint4* rp = (const uint4*)(r_s + lds_pad(64 * t));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint4 q = rp[u];
+            const uint4 q = *(const uint4*)(r_s + 8 * ffast_slot(8 * t + u));
             w[4 * u] = q.x; w[4 * u + 1] = q.y; w[4 * u + 2] = q.z; w[4 * u + 3] = q.w;
         }
     }
