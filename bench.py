@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all (otherwise the dominant kernel is bracketed inside the timed region and "
                          "every kernel in a separate untimed pass)")
+    ap.add_argument("--no-config2", action="store_true", help="skip the extra two-stream (BASELINE config 2) latency measurement")
     ap.add_argument("--dominant", default="k_front",
                     help="kernel (name prefix) bracketed with HIP events inside the timed region: the front-end kernel "
                          "is the one that moves the path's algorithmic bytes (every other kernel works on a few KB per "
@@ -177,7 +178,7 @@ def main():
             ctx.profile_enable(False)
     # BASELINE config 2 (gsm_sync_demod.m on 2 dongle streams): the same call on the first two streams, for the record
     cfg2 = None
-    if rank == 0 and D >= 2 and args.mode == "table" and not use_dist:
+    if rank == 0 and D >= 2 and args.mode == "table" and not use_dist and not args.no_config2:
         def two():
             ctx.check(lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), 2, N, coef_p, len(coef), ts_p, len(ts),
                                                      cf_p, C.c_void_p(table_t.data_ptr()), C.c_void_p(pos_t.data_ptr()), None,
