@@ -1,0 +1,48 @@
+"""Randomised parity sweep of the scanner path (not collected by pytest): N seeded captures through
+gsmcal.fcch_scan_batch and oracle.scan_capture.  Usage: python tests/sweep_scan.py [n_captures] [first_arfcn]"""
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+
+def _one(args):
+    a, kw = args
+    import gsmcal
+    from oracle import gsmcal_oracle as o
+    raw, _ = gsmcal.synth.make_stream(dongle=900, arfcn=a, num_frames=64, **kw)
+    sc = o.scan_capture(raw, gsmcal.synth.fir1(30, 200e3 / gsmcal.synth.FS))
+    return sc["snr"], sc["num_hit"]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import gsmcal
+    rng = np.random.default_rng(first + 1)
+    kws = []
+    for i in range(n):
+        kw = {"bcch": bool(i % 3 != 2)}
+        if i % 4 == 1:
+            kw["snr_db"] = float(rng.uniform(3, 15))
+        kws.append(kw)
+    raw = np.stack([gsmcal.synth.make_stream(dongle=900, arfcn=first + i, num_frames=64, **kws[i])[0] for i in range(n)])
+    out = gsmcal.fcch_scan_batch(raw, gsmcal.synth.fir1(30, 200e3 / gsmcal.synth.FS))
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(_one, [(first + i, kws[i]) for i in range(n)], chunksize=4))
+    bad = 0
+    for i, (snr, nh) in enumerate(res):
+        if nh != out["num_hit"][i] or abs(snr - out["snr"][i]) > 1e-8:
+            bad += 1
+            if bad <= 5:
+                print("mismatch", i, snr, out["snr"][i], nh, out["num_hit"][i])
+    print(f"scan sweep: {n} captures, {int(np.sum(out['num_hit'] > 0))} with hits, {bad} mismatches")
+
+
+if __name__ == "__main__":
+    main()
