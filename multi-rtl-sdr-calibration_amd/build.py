@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gsmcal.hip")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIB_DIR, "libgsmcal.so")
+LIB = os.environ.get("GSMCAL_LIB") or os.path.join(LIB_DIR, "libgsmcal.so")   # GSMCAL_LIB: load another build (tools/devtiming.py)
 
 
 def _deps():

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -75,9 +76,12 @@ struct gsmcal_ctx {
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
+    bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     // shared workspace
-    DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw;
+    DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, csum_head;
+    std::vector<double> h_head;              // partial tap sums uploaded to csum_head (see coarse())
+    unsigned long coef_epoch = 0, head_epoch = ~0ul;   // coef_epoch: bumped whenever h_coef changes
     int tw_n = 0;                            // length the twiddle table was built for
     std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
     int last_S = 0;
@@ -201,6 +205,7 @@ int upload_cached(gsmcal_ctx* c, DevBuf& b, std::vector<double>& host, const dou
     RET_IF(ensure(c, b, n * sizeof(double)));
     host.assign(src, src + n);
     ++c->ws_epoch;
+    if (&host == &c->h_coef) ++c->coef_epoch;
     HIPCHK(c, hipMemcpyAsync(b.p, host.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
@@ -355,25 +360,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                peaks, H, g.NB);
         LAUNCH(c, k_step<STEP_FINE_DECIDE>, dim3(S), dim3(64), 0, st, sa_fine, lvl, 0);
     }
-    if (c->prescreen && c->certify && getenv("GSMCAL_DBG_CERT") && c->cur->cert.p) {   // histogram of the certificate's open chunks
-        (void)hipStreamSynchronize(c->cur->stream);
-        std::vector<FineCert> hc((size_t)S * H);
-        std::vector<StreamState> hs(S);
-        (void)hipMemcpy(hc.data(), c->cur->cert.p, hc.size() * sizeof(FineCert), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(hs.data(), st, (size_t)S * sizeof(StreamState), hipMemcpyDeviceToHost);
-        int hist[34] = {0}, nw = 0;
-        for (int s = 0; s < S; ++s)
-            for (int w = 0; w < hs[s].n_win && w < H; ++w) {
-                const FineCert& f = hc[(size_t)s * H + w];
-                ++hist[f.nch < 0 ? 33 : (f.nch > 32 ? 32 : f.nch)];
-                ++nw;
-                if (getenv("GSMCAL_DBG_CERT")[0] == '2')
-                    fprintf(stderr, "cert s=%d w=%d p=%.6g t=%d k=%d a=%d b=%d nch=%d\n", s, w, f.p, f.t, f.k, f.a, f.b, f.nch);
-            }
-        fprintf(stderr, "fine cert: %d windows; open chunks histogram:", nw);
-        for (int i = 0; i < 34; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
-        fprintf(stderr, "\n");
-    }
     // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
     // and SNR gate fused per burst
     {
@@ -383,36 +369,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                          next_sch_lvl >= 0 ? next_sch_lvl : 0, tl));
         LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
                g.nfft, (const cplx*)c->tw.p, g.ov, 1, tl);
-    }
-    if (getenv("GSMCAL_DBG_BT")) {
-        TailArgs notail;
-        memset(&notail, 0, sizeof(notail));
-        const size_t nb = (size_t)S * H;
-        RET_IF(ensure(c, c->misc, nb * 16 * 8));
-        (void)hipStreamSynchronize(c->cur->stream);
-        (void)hipMemset(c->misc.p, 0, nb * 16 * 8);
-        void* p = c->misc.p;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_dbg), &p, sizeof(p));
-        const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
-        LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
-               g.nfft, (const cplx*)c->tw.p, g.ov, 1, notail);
-        (void)hipStreamSynchronize(c->cur->stream);
-        std::vector<unsigned long long> h(nb * 16);
-        (void)hipMemcpy(h.data(), p, h.size() * 8, hipMemcpyDeviceToHost);
-        void* z = nullptr;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_dbg), &z, sizeof(z));
-        unsigned long long t0 = ~0ull, t1 = 0;
-        double ph[4] = {0, 0, 0, 0};
-        int cnt = 0;
-        for (size_t b = 0; b < nb; ++b) {
-            if (!h[b * 16 + 4]) continue;
-            if (h[b * 16] < t0) t0 = h[b * 16];
-            if (h[b * 16 + 4] > t1) t1 = h[b * 16 + 4];
-            for (int i = 0; i < 4; ++i) ph[i] += (h[b * 16 + i + 1] - h[b * 16 + i]) / 100.0;
-            ++cnt;
-        }
-        fprintf(stderr, "burst_tone<1>: %d blocks, span %.1f us; mean phase us: gather %.1f fft+argmax %.1f tone %.1f gate %.1f\n",
-                cnt, (t1 - t0) / 100.0, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
     }
     CHECK_LAUNCH(c);
     return 0;
@@ -523,7 +479,7 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
     bool sym = (int)c->h_coef.size() == ntaps;                 // linear-phase taps? (fir1 and the .fda designs are)
     for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
     if ((ntaps == 47 || ntaps == 31) && decim == 64 && ((uintptr_t)d_raw & 15) == 0 && ((2 * n) & 15) == 0 &&
-        !getenv("GSMCAL_FRONT_GENERIC")) {
+        !c->front_generic) {
         // the production geometries (fir1(46) / fir1(30), 8x oversampling, aligned captures): rows in registers
         const size_t flds = (size_t)2048 * 16;              // swizzled, unpadded: five workgroups per CU
         c->cur->npartial = (int)nblk * 4;                  // this kernel writes one partial per wave
@@ -546,13 +502,12 @@ int hits_capacity(long len_dec, int dec_ratio) {
     return h;
 }
 
-size_t coarse_scan_lds(long nwin, int mv_len, bool speculate = false) {
-    return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) +
-           (speculate ? (size_t)MAXH * (32 * sizeof(double) + 2 * sizeof(long)) + 144 * sizeof(cplx) : 0) + (size_t)(nwin + mv_len + 128) * sizeof(double);
+size_t coarse_scan_lds(long nwin, int mv_len) {
+    return coarse_scan_lds_fixed() + (size_t)(nwin + mv_len + 128) * sizeof(double);
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
-           bool mean_corr = false, long n0 = 0) {
+           bool mean_corr = false, long n0 = 0, int front_decim = 64) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
     if (mean_corr) {   // input = FIR of the raw bytes (front_fused): DC removed on load
@@ -563,33 +518,37 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
         double cs = 0.0;
         for (double v : c->h_coef) cs += v;
         a.csum_all = cs;
-        a.csum_first = c->h_coef.empty() ? 0.0 : c->h_coef[0];
+        // decimated rows j with front_decim*j < ntaps-1 see only taps 0..front_decim*j (zero initial state of filter())
+        const int ntaps = (int)c->h_coef.size();
+        const int n_head = ntaps > 1 ? (ntaps - 1 + front_decim - 1) / front_decim : 1;
+        if ((int)c->h_head.size() != n_head || c->head_epoch != c->coef_epoch) {
+            c->h_head.assign(n_head, 0.0);
+            for (int j = 0; j < n_head; ++j) {
+                double h = 0.0;
+                for (int k = 0; k < ntaps && k <= (long)front_decim * j; ++k) h += c->h_coef[k];
+                c->h_head[j] = h;
+            }
+            RET_IF(ensure(c, c->csum_head, (size_t)n_head * sizeof(double)));
+            HIPCHK(c, hipMemcpyAsync(c->csum_head.p, c->h_head.data(), (size_t)n_head * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            c->head_epoch = c->coef_epoch;
+            ++c->ws_epoch;
+        }
+        a.csum_head = (const double*)c->csum_head.p;
+        a.n_head = n_head;
     }
     a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
     a.fine_setup_ov = fine_setup_ov;
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
     const long nwin = n_first - (fft_len - 1);
-    // few streams: the kernel is a chain of latencies, so a second wave walks the hops speculatively while the first
-    // replays the running sums; many streams: throughput counts, and the table's LDS would cost occupancy
-    a.speculate = S <= 512 ? 1 : 0;
-    const size_t lds = coarse_scan_lds(n_first, 10 * fft_len, a.speculate != 0);
+    const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
-    if (getenv("GSMCAL_DBG_COARSE")) { RET_IF(ensure(c, c->misc, (size_t)S * 64 + 1024)); a.dbg = (unsigned long long*)c->misc.p; }
     LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
-    if (a.speculate) LAUNCH(c, k_coarse_scan<2>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    // two register budgets of the same kernel: small batches run one workgroup per CU anyway, big ones want four
+    if (S <= 512) LAUNCH(c, k_coarse_scan<2>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     else LAUNCH(c, k_coarse_scan<4>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
-    if (a.dbg) {
-        std::vector<unsigned long long> h((size_t)S * 8);
-        (void)hipStreamSynchronize(c->cur->stream);
-        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
-        for (int i = 0; i < S && i < 64; ++i)
-            fprintf(stderr, "coarse[%d] load %.1f scan %.1f hops %.1f setup %.1f store %.1f us hit %llu n %llu\n", i,
-                    (h[i*8+1]-h[i*8+0]) / 100.0, (h[i*8+2]-h[i*8+1]) / 100.0, (h[i*8+3]-h[i*8+2]) / 100.0,
-                    (h[i*8+4]-h[i*8+3]) / 100.0, (h[i*8+5]-h[i*8+4]) / 100.0, h[i*8+6], h[i*8+7]);
-    }
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -671,12 +630,20 @@ int join_lanes(gsmcal_ctx* c, int nl) {
     return 0;
 }
 
-// Run `enqueue` (which only enqueues work on the context's streams) eagerly, or -- from the third
-// identical call on -- as a captured hipGraph replayed with one hipGraphLaunch.  The first two calls
-// run eagerly so that every workspace buffer, lane stream and event exists before capture starts.
+// Run `enqueue` (which only enqueues work on the context's streams) eagerly, or -- from the second identical
+// call on -- as a captured hipGraph replayed with one hipGraphLaunch.  The first call runs eagerly so that every
+// workspace buffer, lane stream and event exists before capture starts; the second captures, instantiates and
+// replays.  Capture is never attempted where it cannot work -- the legacy NULL stream, or a user stream that is
+// itself being captured (e.g. inside torch.cuda.graph) -- and any capture failure falls back to eager launches.
 template <class F>
 int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vector<uintptr_t>& key, F enqueue) {
-    const bool same = c->use_graph && !c->prof && slot.key == key && slot.epoch == c->ws_epoch;
+    bool can_graph = c->use_graph && !c->prof && c->stream != nullptr;
+    if (can_graph) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); can_graph = false; }
+        else if (cs != hipStreamCaptureStatusNone) can_graph = false;       // the caller is capturing: just enqueue
+    }
+    const bool same = can_graph && slot.key == key && slot.epoch == c->ws_epoch;
     if (same && slot.exec) {
         HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
         return 0;
@@ -687,7 +654,11 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
         slot.seen = 0;
     }
     if (same && slot.seen >= 1) {
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            c->use_graph = false;                       // this stream cannot be captured: eager launches for good
+            return enqueue();
+        }
         c->capturing = true;
         const int rc = enqueue();
         c->capturing = false;
@@ -695,13 +666,15 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
         const hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc < 0 || e != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
-            c->use_graph = false;                       // fall back to eager launches for good
+            (void)hipGetLastError();
+            c->use_graph = false;
             if (rc < 0) return rc;
             return enqueue();
         }
         hipGraphExec_t ex = nullptr;
         if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
             c->use_graph = false;
             return enqueue();
         }
@@ -712,11 +685,11 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
     }
     const int rc = enqueue();
     if (rc < 0) return rc;
-    // the call may have allocated / uploaded: remember the state AFTER it
-    slot.key = key;
-    slot.epoch = c->ws_epoch;
-    slot.seen = same ? slot.seen + 1 : 1;
-    if (!same) slot.seen = 1;
+    if (can_graph) {                                    // the call may have allocated / uploaded: remember the state AFTER it
+        slot.key = key;
+        slot.epoch = c->ws_epoch;
+        slot.seen = 1;
+    }
     return rc;
 }
 
@@ -775,6 +748,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (ce) c->certify = atoi(ce) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
+    const char* fg = getenv("GSMCAL_FRONT_GENERIC");
+    if (fg && atoi(fg) != 0) c->front_generic = true;
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
     *out = c;
@@ -801,7 +776,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->coef, &c->ts, &c->cf, &c->table, &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen,
-                      &c->misc, &c->tw};
+                      &c->misc, &c->tw, &c->csum_head};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
@@ -1113,9 +1088,12 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
     if (st.status < 0) return st.status;
     if (sampling_ppm) *sampling_ppm = st.sampling_ppm2;
     if (st.n_rows == 0) {
-        pos_info[0] = -1.0;
-        pos_info[cap_rows] = -1.0;
-        *num_rows = 1;
+        // the reference's all -1 sentinel keeps the shape of the exit taken: [-1 -1] (:9, :61) or the -ones(3K,2)
+        // pre-allocation of :32 (fewer than 5 SCH :84, spacing failure :106-112) -- gsm_sync_demod.m:130 counts its rows
+        const int nr = st.n_sent_rows > 0 ? st.n_sent_rows : 1;
+        if (nr > cap_rows) return GSMCAL_E_CAPACITY;
+        for (int i = 0; i < nr; ++i) { pos_info[i] = -1.0; pos_info[cap_rows + i] = -1.0; }
+        *num_rows = nr;
     } else {
         if (st.n_rows > cap_rows) return GSMCAL_E_CAPACITY;
         for (int i = 0; i < st.n_rows; ++i) {
@@ -1226,6 +1204,10 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // ..FCCH_scanner.m:43-45
     const long nd = (n + decim - 1) / decim;
     if (hits_capacity(nd, dec_ratio) > MAXH) return GSMCAL_E_CAPACITY;
+    if (nd < (long)ceil(23.0 * 1250.0 / (double)dec_ratio)) {   // FCCH_coarse_position.m:25 s(1:ceil(23 frames)): MATLAB index error
+        c->err = "capture shorter than 23 frames after decimation (FCCH_coarse_position.m:25 would index past the end)";
+        return GSMCAL_E_INDEX;
+    }
     c->cur = &c->lanes[0];
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
@@ -1241,7 +1223,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
@@ -1315,7 +1297,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n));         // :117 (+ state init, fine setup)
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));         // :117 (+ state init, fine setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;
         RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts));                              // :118 (+ SCH window setup)
@@ -1399,5 +1381,67 @@ int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* 
     }
     return 0;
 }
+
+#ifdef GSMCAL_DEVTIMING
+// Development build only: in-kernel phase timestamps (state.h DEV_STAMP).  begin() arms a zeroed buffer, report()
+// prints, per kernel, the span of the launch and the mean time between consecutive stamps of a block.
+static void* g_stamp_buf = nullptr;
+int gsmcal_devtiming_begin(gsmcal_ctx* c) {
+    if (!c) return GSMCAL_E_ARG;
+    const size_t bytes = (size_t)KID_N * DEV_STAMP_BLOCKS * 16 * sizeof(unsigned long long);
+    HIPCHK(c, hipDeviceSynchronize());
+    if (!g_stamp_buf) HIPCHK(c, hipMalloc(&g_stamp_buf, bytes));
+    HIPCHK(c, hipMemset(g_stamp_buf, 0, bytes));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &g_stamp_buf, sizeof(g_stamp_buf)));
+    return 0;
+}
+int gsmcal_devtiming_report(gsmcal_ctx* c) {
+    if (!c || !g_stamp_buf) return GSMCAL_E_ARG;
+    static const char* names[KID_N] = {"coarse_snr", "coarse_scan", "gather", "cert", "chunk", "verify", "burst_tone<1>", "window_sch", "burst_tone<0>", "front"};
+    HIPCHK(c, hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)KID_N * DEV_STAMP_BLOCKS * 16);
+    HIPCHK(c, hipMemcpy(h.data(), g_stamp_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    void* z = nullptr;
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &z, sizeof(z)));
+    for (int k = 0; k < KID_N; ++k) {
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double ph[15] = {0}; int pc[15] = {0}; int nb = 0;
+        for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
+            const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];
+            if (!r[0]) continue;
+            ++nb;
+            if (r[0] < t0) t0 = r[0];
+            unsigned long long prev = r[0];
+            for (int i = 1; i < 16; ++i) {
+                if (!r[i]) continue;
+                if (r[i] > t1) t1 = r[i];
+                ph[i - 1] += (double)(r[i] - prev) / 100.0; ++pc[i - 1];
+                prev = r[i];
+            }
+        }
+        if (!nb) continue;
+        std::vector<double> st0, en0;
+        for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
+            const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];
+            if (!r[0]) continue;
+            unsigned long long e = r[0];
+            for (int i = 1; i < 16; ++i) if (r[i] > e) e = r[i];
+            st0.push_back((double)(r[0] - t0) / 100.0);
+            en0.push_back((double)(e - t0) / 100.0);
+        }
+        std::sort(st0.begin(), st0.end());
+        std::sort(en0.begin(), en0.end());
+        static unsigned long long g0 = 0;
+        if (k == 0 || !g0) g0 = t0;
+        fprintf(stderr, "devtiming abs [%7.1f .. %7.1f] ", ((double)t0 - (double)g0) / 100.0, ((double)t1 - (double)g0) / 100.0);
+        fprintf(stderr, "devtiming %-14s blocks %4d span %7.1f us | start p50 %.1f p90 %.1f max %.1f | end p50 %.1f p90 %.1f | phases:", names[k], nb,
+                t1 > t0 ? (double)(t1 - t0) / 100.0 : 0.0, st0[st0.size() / 2], st0[st0.size() * 9 / 10], st0.back(),
+                en0[en0.size() / 2], en0[en0.size() * 9 / 10]);
+        for (int i = 0; i < 15; ++i) if (pc[i]) fprintf(stderr, " [%d->%d] %.1f (n=%d)", i, i + 1, ph[i] / pc[i], pc[i]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -74,12 +74,15 @@ __device__ __forceinline__ double snr_from_power(const double (&P)[L]) {
 // With corr == 0 the view is a plain array (API paths, exact reference operation order).
 struct DecView {
     const cplx* s;
-    double cr, ci;      // mean * sum(coef)        (subtracted from every sample j >= 1)
-    double c0r, c0i;    // mean * coef[0]          (sample 0: zero initial state)
+    double cr, ci;      // mean * sum(coef)        (subtracted from every sample j >= n_head)
+    double mr, mi;      // the mean itself, for the head rows
+    const double* head; // head[j] = sum_{k <= min(ntaps-1, decim*j)} coef[k], j < n_head: the rows whose filter()
+    int n_head;         // window still overlaps the zero initial state (row 0 only when ntaps <= decim + 1)
 };
 __device__ __forceinline__ cplx dv_load(const DecView& v, long j) {
     const cplx x = v.s[j];
-    return j == 0 ? make_double2(x.x - v.c0r, x.y - v.c0i) : make_double2(x.x - v.cr, x.y - v.ci);
+    if (j < v.n_head) { const double h = v.head[j]; return make_double2(x.x - v.mr * h, x.y - v.mi * h); }
+    return make_double2(x.x - v.cr, x.y - v.ci);
 }
 
 __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
@@ -141,6 +144,12 @@ __device__ __forceinline__ double window_snr(const DecView& s, long start, int f
     return fft_len == 16 ? window_snr16(s, start) : window_snr_generic(s, start, fft_len, tw);
 }
 
+// DC removal of a sample that was loaded raw (the hop walk's look-ahead fetch): same arithmetic as dv_load
+__device__ __forceinline__ cplx dv_fix(const DecView& v, cplx x, long j) {
+    if (j < v.n_head) { const double h = v.head[j]; return make_double2(x.x - v.mr * h, x.y - v.mi * h); }
+    return make_double2(x.x - v.cr, x.y - v.ci);
+}
+
 struct CoarseArgs {
     const cplx* s; long s_stride; long len;   // decimated streams
     int decimation_ratio;                     // FCCH_coarse_position's 2nd argument
@@ -149,12 +158,11 @@ struct CoarseArgs {
     long t_lo, t_hi; double avg_snr;          // mode 2: target_set and fixed average
     double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
     int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
-    unsigned long long* dbg;                  // optional: 8 timestamps per stream (development aid)
-    double csum_all, csum_first;              // > 0 taps: the input is the FIR of the raw bytes; remove mean*csum on load
+    double csum_all;                          // mean_corr: the input is the FIR of the raw bytes; remove mean*csum on load
+    const double* csum_head; int n_head;      //            partial tap sums of the rows that overlap filter()'s zero initial state
     int mean_corr;
     const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
     int npartial; long n0;                    //            and the capture length they divide by
-    int speculate;                            // mode 0, few streams: walk the hops speculatively beside the exact scan
 };
 
 // raw2iq.m:8 from the front kernel's per-block partial sums: exact integer totals, one fp64 divide each
@@ -183,7 +191,9 @@ __device__ __forceinline__ DecView dec_view(const CoarseArgs& a, int stream, dou
     v.s = a.s + (size_t)stream * a.s_stride;
     const double m = a.mean_corr ? 1.0 : 0.0;
     v.cr = m * mean_re * a.csum_all;   v.ci = m * mean_im * a.csum_all;
-    v.c0r = m * mean_re * a.csum_first; v.c0i = m * mean_im * a.csum_first;
+    v.mr = mean_re; v.mi = mean_im;
+    v.head = a.csum_head;
+    v.n_head = a.mean_corr ? a.n_head : 0;
     return v;
 }
 
@@ -226,49 +236,92 @@ __global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
     double mr = 0.0, mi = 0.0;
     if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }
     const DecView s = dec_view(a, blockIdx.y, mr, mi);
+    DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 0);
     a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s, i, g.fft_len, tw);
+    DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
 
 __device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl);   // kernels_estim.h
 
-// ---- k_coarse_scan: the serial part of the detector, one workgroup per stream ----
-// grid S, block 256.  LDS: state copy | 64 twiddles | snr[nwin].
+// ---- k_coarse_scan: first hit + hop walk of FCCH_coarse_position, one workgroup per stream ----
+// grid S, block 256.  LDS: state copy | 64 twiddles | 4 x 36 hop samples | 2 x 11 x 17 hop powers | snr[mv_len + nwin + 64].
 //
-// move_fft_snr_runtime_avg's loop is serial only through sum_snr (two dependent fp64 adds per window,
-// :37-38).  Wave 0 replays the reference's running-sum updates in the reference's order, 64 windows
-// at a time: every lane advances the same (wave-uniform) sum from broadcast LDS reads, lane j keeps
-// the sum window j sees, then the 64 lanes evaluate snr - sum/mv_len > th (the true fp64 divide of
-// :30) and a ballot picks the first hit.  Updates past a hit are never used -- the `break`.
-// Then the hop loop of FCCH_coarse_position.m:32-86 (both the +10-frame and the +11-frame candidate
-// windows of a hop are evaluated together; the +11 ones are only consulted when the +10 ones miss).
-// WAVES: minimum waves per SIMD the register allocator must leave room for -- 2 for the latency-bound small batches
-// (no spills, speculative hop walk), 4 for the big ones (four workgroups per CU; the spills sit off the hot chain).
+// (1) First hit, move_fft_snr_runtime_avg.m:30-42.  The loop is serial only through the ROUNDING of sum_snr (two
+// dependent fp64 adds per window); its decisions (snr - sum_snr/mv_len > th) almost never depend on that rounding.
+// Each thread takes a run of windows, sums the mv_len entries its first window sees directly and slides from there.
+// These sums differ from the reference's serially rounded ones by at most
+//     (2 nwin + mv_len + 2 per) * 2^-53 * mv_len * V     (every fp64 add errs by <= 2^-53 |result|, |result| <= mv_len V,
+//                                                         V = 1000 >= |snr| checked per window, the seed is 999)
+// i.e. <= 1e-9 on the average for the reference geometry.  A window whose margin to the threshold exceeds `delta`
+// (1e-6 + 4x that bound) is decided for good, and the first decided hit stands if no undecided window precedes it.
+// Otherwise (a margin inside delta, a non-finite SNR) wave 0 replays the reference's running-sum updates in the
+// reference's order, 64 windows at a time: every lane advances the same wave-uniform sum from broadcast LDS reads,
+// lane j keeps the sum window j sees, then the 64 lanes evaluate snr - sum/mv_len > th with the true divide of :30
+// and a ballot picks the first hit (~18 ns per window: the latency of two dependent v_add_f64).  mode 1 -- the API's
+// move_fft_snr_runtime_avg, which REPORTS hit_avg_snr -- always takes the exact replay.
+// (2) Hop walk, FCCH_coarse_position.m:32-86 + specific_fft_snr_fix_avg.m:10-25, by wave 0.  A hop looks at the 11
+// windows around +10 frames and, if those all miss, the 11 around +11 frames.  All 22 spectra of a hop come from one
+// pass: lane (group, half, bin k) takes bin k of its half's first window by a direct 16-point DFT and slides it
+// through the next windows (X_k(t+1) = (X_k(t) + x[t+16] - x[t]) e^{+2 pi i k/16}); the powers go through LDS to
+// 22 lanes that form the SNRs (first max, 3 bins, log10) and a ballot applies the reference's first-hit rule.  The
+// samples the NEXT hop can ask for are known one hop early (4 rows of 36 for the four (branch, group) pairs), so
+// every hop also fetches those and the following hop finds its windows in LDS.  With a certified average
+// (1) the hop decisions carry the same delta check; a decision inside delta repeats the stream with the exact replay.
+// WAVES: minimum waves per SIMD the register allocator must leave room for (2: small batches, 4: four workgroups per CU).
+#define CS_ROW 36
+__host__ __device__ inline size_t coarse_scan_lds_fixed() {
+    return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + 4 * CS_ROW * sizeof(cplx) + (2 * 11 * 17 + 2 * MAXH) * sizeof(double);
+}
+
 template <int WAVES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
     __shared__ double sh_avg;  // sum/mv_len seen by the hit window
-    __shared__ int sh_pred;    // predicted first hit (approximate sums), INT_MAX if none
-    __shared__ int sh_nspec;   // hops the speculative walk recorded
+    __shared__ int sh_pred;    // first window the certificate decided as a hit, INT_MAX if none
+    __shared__ int sh_unc;     // first window the certificate could not decide, INT_MAX if none
+    __shared__ int sh_exact;   // 1: run the exact serial replay
+    __shared__ int sh_redo;    // a hop decision sat inside delta: repeat with the exact replay
     StreamState* st = (StreamState*)smem;                 // LDS copy of the stream state
     cplx* tw = (cplx*)(smem + ((sizeof(StreamState) + 15) & ~(size_t)15));
-    double* spec_v = (double*)(tw + 64);                  // MAXH x 32: candidate SNRs of the speculative hop walk
-    long* spec_nx = (long*)(spec_v + MAXH * 32);          // MAXH x 2: the (nx0, nx1) each row belongs to
-    cplx* pfb = (cplx*)(spec_nx + MAXH * 2);              // 4 x 36 samples fetched one hop ahead
-    constexpr bool SPEC = WAVES < 4;                      // the large-batch build carries no speculation code at all
-    double* snr_s = (SPEC && a.speculate) ? (double*)(pfb + 144) : spec_v;   // (none of these without speculation)
+    cplx* rows = tw + 64;                                 // 4 x CS_ROW samples of the current hop
+    double* Pb = (double*)(rows + 4 * CS_ROW);            // [group][window][17]: powers of the hop's 22 windows
+    double* hop_sig_base = Pb + 2 * 11 * 17;             // (signal, noise) of the hit each hop settled on
+    double* snr_s = hop_sig_base + 2 * MAXH;
     StreamState* st_g = sts + blockIdx.x;
-    double mr0 = 0.0, mi0 = 0.0;
-    unsigned long long ti0 = 0, tq0 = 0;
-    if (a.mean_corr) stream_mean(a, blockIdx.x, &mr0, &mi0, &ti0, &tq0);      // batch path: means from the front kernel
-    const DecView s = dec_view(a, blockIdx.x, a.mean_corr ? mr0 : st_g->mean_re, a.mean_corr ? mi0 : st_g->mean_im);
     const long len = a.len;
     const CoarseGeom g = coarse_geom(a);
     const int fft_len = g.fft_len, mv_len = g.mv_len;
     const double th = g.th;
     const int tid = threadIdx.x;
-#define CS_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define CS_STAMP(i) DEV_STAMP(KID_COARSE_SCAN, blockIdx.x, i)
     CS_STAMP(0);
+    const bool bad = fft_len > 64 || fft_len < 2 || g.n_first > len;   // s(1:n_first): MATLAB index error
+    // padded copy S = [999 x mv_len | snr[0..nwin) | 0 x 64]: S[q] is the SNR evicted by window q
+    // (999 while the history still holds its seed, move_fft_snr_runtime_avg.m:11), S[mv_len+q] is
+    // window q's own SNR; every load of the unrolled recurrence below is unconditional.  The global loads go out
+    // first, 16 per lane in flight, and everything else of the prologue runs under their latency.
+    if (!bad && a.mode != 2) {
+        const double* sg = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
+        const long tot = mv_len + g.nwin + 64;
+        for (long i0 = 0; i0 < tot; i0 += 16 * 256) {
+            double rv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const long i = i0 + tid + 256 * u;
+                rv[u] = (i >= mv_len && i < mv_len + g.nwin) ? sg[i - mv_len] : (i < mv_len ? 999.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const long i = i0 + tid + 256 * u;
+                if (i < tot) snr_s[i] = rv[u];
+            }
+        }
+    }
+    double mr0 = 0.0, mi0 = 0.0;
+    unsigned long long ti0 = 0, tq0 = 0;
+    if (a.mean_corr) stream_mean(a, blockIdx.x, &mr0, &mi0, &ti0, &tq0);      // batch path: means from the front kernel
+    const DecView s = dec_view(a, blockIdx.x, a.mean_corr ? mr0 : st_g->mean_re, a.mean_corr ? mi0 : st_g->mean_im);
     if (a.mean_corr) {
         // batch path: this kernel is the first to touch the stream's state -- build it from scratch in LDS (all zero,
         // then the sentinels the reference functions start from), no memset / finish-mean launches needed
@@ -288,17 +341,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         uint4* dst = (uint4*)st;
         for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
     }
-    coarse_twiddles(tw, fft_len, tid, 256);
-    const bool bad = fft_len > 64 || fft_len < 2 || g.n_first > len;   // s(1:n_first): MATLAB index error
-    // padded copy S = [999 x mv_len | snr[0..nwin) | 0 x 64]: S[q] is the SNR evicted by window q
-    // (999 while the history still holds its seed, move_fft_snr_runtime_avg.m:11), S[mv_len+q] is
-    // window q's own SNR; every load of the unrolled recurrence below is unconditional.
-    if (!bad && a.mode != 2) {
-        const double* sg = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
-        for (long i = tid; i < mv_len + g.nwin + 64; i += 256)
-            snr_s[i] = i < mv_len ? 999.0 : (i < mv_len + g.nwin ? sg[i - mv_len] : 0.0);
-    }
+    if (fft_len >= 2 && fft_len <= 64)
+        for (int i = tid; i < fft_len; i += 256) {
+            double sn, cs;
+            sincospi(-2.0 * (double)i / (double)fft_len, &sn, &cs);
+            tw[i] = make_double2(cs, sn);
+        }
     __syncthreads();
+    const bool want_cert = !bad && a.mode == 0;
     if (tid == 0) {
         st->n_coarse = 0;
         st->coarse_hit_flag = 0;
@@ -307,38 +357,79 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         st->mv_hit_snr = INFINITY;
         sh_hit = 0x7fffffff;
         sh_pred = 0x7fffffff;
-        sh_nspec = 0;
+        sh_unc = 0x7fffffff;
+        sh_exact = want_cert ? 0 : 1;
+        sh_redo = 0;
         if (bad) set_status(st, 3, GSMCAL_E_INDEX);
     }
     __syncthreads();
     int n = 0;
     CS_STAMP(1);
-    // ---- prediction (mode 0): where will the exact running-average scan hit?  Each thread takes a run of
-    // windows, sums the mv_len entries its first window sees directly and slides from there; the sums differ
-    // from the reference's serially rounded ones by ~1e-12, so the predicted first hit is the exact one unless
-    // a window sits within that of the threshold.  Only the SPECULATION below depends on it, never a result.
-    if (SPEC && !bad && a.mode == 0 && a.speculate) {
-        const int per = (int)((g.nwin + 255) / 256);
-        const int j0 = tid * per, j1 = j0 + per < (int)g.nwin ? j0 + per : (int)g.nwin;
+    const double cert_V = 1000.0;
+    const int sc_total = mv_len + (int)g.nwin;            // entries of S that windows can see
+    const int sc_per = (sc_total + 255) / 256;            // entries (and windows) per thread
+    const double cert_delta = 1e-6 + 4.0 * 1.1102230246251565e-16 * cert_V *
+                              ((2.0 * (double)g.nwin + (double)mv_len + 64.0) +
+                               2.0 * ((double)sc_per + 32.0) * (double)sc_total / (double)mv_len);
+    if (want_cert) {
+        // window sums from a block-wide prefix scan of S: C[p] = sum_{i<p} S[i] at every thread's chunk start (Cb) plus
+        // a partial chunk sum; window j sees C[j+mv_len] - C[j].  (<= sc_per + 32 fp64 adds of magnitude <= sc_total V per
+        // C value: the second term of cert_delta.)
+        __shared__ double sh_ws[4];
+        double* Cb = (double*)rows;                        // 257 doubles; the hop buffers are not in use yet
+        const int lane = tid & 63, wave = tid >> 6;
+        const int p0 = tid * sc_per;
+        double loc = 0.0;
+        for (int i = 0; i < sc_per; ++i) loc += (p0 + i < sc_total) ? snr_s[p0 + i] : 0.0;
+        double inc = loc;
+        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+        if (lane == 63) sh_ws[wave] = inc;
+        __syncthreads();
+        double base = 0.0;
+        for (int i = 0; i < wave; ++i) base += sh_ws[i];
+        Cb[tid] = base + (inc - loc);
+        if (tid == 255) Cb[256] = base + inc;
+        __syncthreads();
+        const int j0 = p0, j1 = j0 + sc_per < (int)g.nwin ? j0 + sc_per : (int)g.nwin;
         if (j0 < j1) {
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            int q = 0;
-            for (; q + 4 <= mv_len; q += 4) { q0 += snr_s[j0 + q]; q1 += snr_s[j0 + q + 1]; q2 += snr_s[j0 + q + 2]; q3 += snr_s[j0 + q + 3]; }
-            for (; q < mv_len; ++q) q0 += snr_s[j0 + q];
-            double sm = (q0 + q1) + (q2 + q3);
+            const int idx = j0 + mv_len, bq = idx / sc_per, rq = idx - bq * sc_per;
+            double cx = Cb[bq];
+            for (int i = 0; i < rq; ++i) cx += snr_s[bq * sc_per + i];
+            double sm = cx - Cb[tid];
             const double inv = 1.0 / (double)mv_len;
             for (int j = j0; j < j1; ++j) {
-                if (snr_s[mv_len + j] - sm * inv > th) { atomicMin(&sh_pred, j); break; }
-                sm += snr_s[mv_len + j] - snr_s[j];
+                const double v = snr_s[mv_len + j];
+                const double mg = (v - sm * inv) - th;
+                if (!(fabs(v) <= cert_V) || !(fabs(mg) > cert_delta)) { atomicMin(&sh_unc, j); break; }   // (NaN lands here)
+                if (mg > 0.0) { atomicMin(&sh_pred, j); break; }
+                sm += v - snr_s[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // the average the decided hit sees (64 lanes + a shuffle tree: within the same bound)
+            const int pred = sh_pred;
+            const bool ok = !(sh_unc < pred);
+            double sm = 0.0;
+            if (ok && pred != 0x7fffffff) {
+                for (int q = tid; q < mv_len; q += 64) sm += snr_s[pred + q];
+                for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+            }
+            if (tid == 0) {
+                if (!ok) sh_exact = 1;
+                else if (pred != 0x7fffffff) { sh_hit = pred; sh_avg = sm / (double)mv_len; }
             }
         }
         __syncthreads();
     }
+    CS_STAMP(2);
     if (!bad && a.mode != 2) {
+      for (int pass = 0; pass < 2; ++pass) {               // pass 1 only after a hop decision fell inside delta
         // ---- move_fft_snr_runtime_avg ----
         const long nwin = g.nwin;
         const double dmv = (double)mv_len;
-        if (tid < 64) {
+        const bool exact = sh_exact != 0;                  // block-uniform
+        if (tid < 64 && exact) {
             const int lane = tid;
             // :11-12 store = 999*ones(1,mv_len); sum_snr = sum(store): sequential sum of 999s (wave-uniform)
             double sum_snr = 0.0;
@@ -374,121 +465,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 }
             }
         }
-        else if (SPEC && tid < 128 && a.mode == 0 && sh_pred != 0x7fffffff) {
-            // ---- wave 1, while wave 0 replays the exact sums: walk the hops of FCCH_coarse_position.m:32-86 from the
-            // PREDICTED hit and keep every candidate SNR it evaluates.  The SNRs are exact (they do not depend on
-            // the prediction); the real walk below takes them from the table whenever it asks for the same windows.
-            const int lane = tid - 64;
-            const int pred = sh_pred;
-            double sm = 0.0;                                     // approximate average the predicted hit sees
-            for (int q = lane; q < mv_len; q += 64) sm += snr_s[pred + q];
-            for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
-            const double h_snr = snr_s[mv_len + pred];
-            const double avg_pred = h_snr - (h_snr - sm / (double)mv_len);
-            const int dec = a.decimation_ratio;
-            const long d0 = (long)round(12500.0 / (double)dec), d1 = (long)round(13750.0 / (double)dec);
-            const int max_offset = 5, nt = 2 * max_offset + 1;
-            const long limit = (len - (fft_len - 1)) - max_offset;
-            long cur = pred + 1;
-            int ns = 0;
-            // One hop costs a global round trip (~2 us) plus ~0.8 us of arithmetic.  The samples the NEXT hop can
-            // ask for are known one hop early -- its candidates start at nxt + d - 11 + [0,20] for nxt in {nx0, nx1},
-            // d in {d0, d1}, whatever this hop finds -- so every hop also fetches those 4 x 36 samples (three per
-            // lane) and the following hop takes its windows from LDS.
-            cplx pf0 = make_double2(0.0, 0.0), pf1 = pf0, pf2 = pf0;
-            long pbase0 = 0, pbase1 = 0;                         // nx0 - 11, nx1 - 11 of the hop that prefetched
-            bool have_pf = false, took1 = false;
-            while (ns < MAXH - 1) {
-                const long nx0 = cur + d0, nx1 = cur + d1;
-                if (nx0 > limit) break;
-                const long ws = lane < nt ? nx0 - max_offset - 1 + lane : nx1 - max_offset - 1 + (lane - nt);
-                const bool want = lane < nt || (lane < 2 * nt && nx1 <= limit);
-                bool from_lds = false;
-                if (have_pf && fft_len == 16) {
-                    pfb[lane] = pf0; pfb[lane + 64] = pf1;
-                    if (lane + 128 < 144) pfb[lane + 128] = pf2;   // (one wave: its LDS operations stay in order)
-                    const int r = (took1 ? 2 : 0) + (lane < nt ? 0 : 1);
-                    const long off = ws - ((took1 ? pbase1 : pbase0) + (lane < nt ? d0 : d1));
-                    from_lds = want && off >= 0 && off <= 20;
-                    if (!from_lds) { /* direct loads below */ }
-                    else { /* value computed after the next prefetch is issued */ }
-                    // issue the next hop's prefetch before any arithmetic
-                    cplx n0 = make_double2(0.0, 0.0), n1 = n0, n2 = n0;
-                    {
-                        const long b0 = nx0 - 11, b1 = nx1 - 11;
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            const int q = lane + 64 * u;
-                            if (q < 144) {
-                                const int rr = q / 36, i = q - rr * 36;
-                                const long gi = ((rr & 2) ? b1 : b0) + ((rr & 1) ? d1 : d0) + i;
-                                const bool ok = gi >= 0 && gi < len && !((rr & 2) && nx1 > limit);
-                                const cplx t = ok ? dv_load(s, gi) : make_double2(0.0, 0.0);
-                                if (u == 0) n0 = t; else if (u == 1) n1 = t; else n2 = t;
-                            }
-                        }
-                    }
-                    double v = -INFINITY;
-                    if (from_lds) v = window_snr16_buf(pfb + r * 36 + (int)off);
-                    else if (want) v = window_snr(s, ws, fft_len, tw);
-                    pf0 = n0; pf1 = n1; pf2 = n2;
-                    pbase0 = nx0 - 11; pbase1 = nx1 - 11;
-                    if (lane < 32) spec_v[ns * 32 + lane] = v;
-                    if (lane == 0) { spec_nx[2 * ns] = nx0; spec_nx[2 * ns + 1] = nx1; }
-                    ++ns;
-                    const unsigned long long hits = __ballot(v - avg_pred > th);
-                    const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
-                    int found;
-                    long nxt;
-                    if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; took1 = false; }
-                    else {
-                        if (nx1 > limit || !h1) break;
-                        found = nt + __ffsll((long long)h1) - 1;
-                        nxt = nx1;
-                        took1 = true;
-                    }
-                    cur = nxt - max_offset + (found >= nt ? found - nt : found);
-                    continue;
-                }
-                // first hop (or a detector length without the 16-point fast path): direct loads; start the pipeline
-                if (fft_len == 16) {
-                    const long b0 = nx0 - 11, b1 = nx1 - 11;
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int q = lane + 64 * u;
-                        if (q < 144) {
-                            const int rr = q / 36, i = q - rr * 36;
-                            const long gi = ((rr & 2) ? b1 : b0) + ((rr & 1) ? d1 : d0) + i;
-                            const bool ok = gi >= 0 && gi < len && !((rr & 2) && nx1 > limit);
-                            const cplx t = ok ? dv_load(s, gi) : make_double2(0.0, 0.0);
-                            if (u == 0) pf0 = t; else if (u == 1) pf1 = t; else pf2 = t;
-                        }
-                    }
-                    pbase0 = b0; pbase1 = b1;
-                    have_pf = true;
-                }
-                double v = -INFINITY;
-                if (want) v = window_snr(s, ws, fft_len, tw);
-                if (lane < 32) spec_v[ns * 32 + lane] = v;
-                if (lane == 0) { spec_nx[2 * ns] = nx0; spec_nx[2 * ns + 1] = nx1; }
-                ++ns;
-                const unsigned long long hits = __ballot(v - avg_pred > th);
-                const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
-                int found;
-                long nxt;
-                if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; took1 = false; }
-                else {
-                    if (nx1 > limit || !h1) break;
-                    found = nt + __ffsll((long long)h1) - 1;
-                    nxt = nx1;
-                    took1 = true;
-                }
-                cur = nxt - max_offset + (found >= nt ? found - nt : found);
-            }
-            if (lane == 0) sh_nspec = ns;
-        }
         __syncthreads();
-        CS_STAMP(2);
+        CS_STAMP(3);
         const int hit = sh_hit;
         if (hit != 0x7fffffff && tid == 0) {
             const double h_snr = snr_s[mv_len + hit];
@@ -503,58 +481,214 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
             if (hit == 0x7fffffff) {
                 if (tid == 0) set_status(st, 3, GSMCAL_S_NO_FCCH);
             } else {
-                // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units) ----
+                // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units), whole block ----
+                __shared__ long sh_cur;
+                __shared__ int sh_stop, sh_need1, sh_took1;
+                const int lane = tid & 63;
                 const double hit_avg_snr = st->hit_avg_snr;
                 const int dec = a.decimation_ratio;
                 const long d0 = (long)round(12500.0 / (double)dec);     // :35 round() half away from zero
                 const long d1 = (long)round(13750.0 / (double)dec);     // :36
-                const int max_offset = 5;
+                const int max_offset = 5, nt = 2 * max_offset + 1;
                 const long limit = (len - (fft_len - 1)) - max_offset;
                 long cur = hit + 1;
                 n = 1;
                 if (tid == 0) {
                     st->coarse_pos[0] = (double)((cur - 1) * dec + 1);  // :91
                     st->coarse_snr[0] = st->mv_hit_snr;
+                    sh_stop = 0; sh_need1 = 0; sh_took1 = 0;
                 }
-                // wave 0 only, no barriers: lanes 0..10 evaluate the +10-frame candidates, lanes 11..21 the
-                // +11-frame ones (consulted only when the former all miss); ballots keep everything uniform
-                const int nt = 2 * max_offset + 1;
-                if (tid < 64) {
-                    const int lane = tid;
-                    while (n < MAXH) {
-                        const long nx0 = cur + d0, nx1 = cur + d1;
-                        if (nx0 > limit) break;                              // :49
-                        double v = -INFINITY;
-                        const int hs = n - 1;                                // this hop's row of the speculative walk
-                        if (SPEC && hs < sh_nspec && spec_nx[2 * hs] == nx0 && spec_nx[2 * hs + 1] == nx1) {
-                            if (lane < 2 * nt) v = spec_v[hs * 32 + lane];   // same windows: same SNRs, already computed
-                        } else if (lane < nt) v = window_snr(s, nx0 - max_offset - 1 + lane, fft_len, tw);
-                        else if (lane < 2 * nt && nx1 <= limit)
-                            v = window_snr(s, nx1 - max_offset - 1 + (lane - nt), fft_len, tw);
-                        const unsigned long long hits = __ballot(v - hit_avg_snr > th);   // NaN / -inf compare false
-                        const unsigned long long h0 = hits & ((1ull << nt) - 1), h1 = (hits >> nt) & ((1ull << nt) - 1);
-                        int found;
-                        long nxt;
-                        if (h0) { found = __ffsll((long long)h0) - 1; nxt = nx0; }
-                        else {
-                            if (nx1 > limit) break;                          // :67
-                            if (!h1) break;
-                            found = nt + __ffsll((long long)h1) - 1;         // :65 across the idle frame
-                            nxt = nx1;
+                // Certified decisions without the logarithm: 10 log10(sig/noise) - hit_avg_snr > th  <=>  sig/noise > R,
+                // R = 10^((hit_avg_snr + th)/10).  The reference's rounded evaluation sits within 1e-12 dB of the true
+                // value and hit_avg_snr within cert_delta of the exactly replayed one, so sig > R (1 + eps) noise is a
+                // hit and sig < R (1 - eps) noise a miss for good, eps = 0.2303 cert_delta + 1e-12 (d(ratio)/ratio =
+                // ln(10)/10 per dB); anything in between sends the stream to the exact replay.  Only the SNR of the
+                // hit a hop settles on is reported: those logarithms are taken after the walk, one lane per hop.
+                const double R = exp10((hit_avg_snr + th) / 10.0);
+                const double r_eps = 0.2303 * cert_delta + 1e-12;
+                const double Rhi = R * (1.0 + r_eps), Rlo = R * (1.0 - r_eps);
+                double* hop_sig = hop_sig_base;
+                const bool fast = fft_len == 16;
+                const bool ratio_mode = !exact && fast;
+                // loader threads (tid < 4*CS_ROW): one look-ahead sample each; spectrum threads (tid < 11*16): one
+                // (window, bin) each; wave 0 lanes < 11 turn a group's powers into decisions
+                cplx pf = make_double2(0.0, 0.0);
+                long pg = -1;
+                long pbase0 = 0, pbase1 = 0;                               // nx0 - 11, nx1 - 11 of the hop that fetched the rows
+                bool have_pf = false;
+                const cplx* sraw = s.s;
+                const int dw = tid >> 4, dk = tid & 15;                    // spectrum role
+                __syncthreads();
+#ifdef GSMCAL_DEVTIMING
+                unsigned long long cyc[5] = {0, 0, 0, 0, 0}, c0 = 0;
+#define HOP_CYC(i) do { const unsigned long long c1 = __builtin_readcyclecounter(); cyc[i] += c1 - c0; c0 = c1; } while (0)
+#else
+#define HOP_CYC(i) do { } while (0)
+#endif
+                while (n < MAXH) {                                         // (cur, n: block-uniform)
+                    const long nx0 = cur + d0, nx1 = cur + d1;
+                    if (nx0 > limit) break;                              // :49
+#ifdef GSMCAL_DEVTIMING
+                    c0 = __builtin_readcyclecounter();
+#endif
+                    const bool g1ok = nx1 <= limit;
+                    const bool took1 = sh_took1 != 0;
+                    int r0 = 0, r1 = 1, off0 = 0, off1 = 0;              // row and offset of each group's first window (start nx - 6)
+                    if (fast) {
+                        if (have_pf) {
+                            // DC removal (DecView) on the way into LDS: the loads themselves were issued a hop ago
+                            if (tid < 4 * CS_ROW) rows[tid] = pg < 0 ? make_double2(0.0, 0.0) : dv_fix(s, pf, pg);
+                            r0 = took1 ? 2 : 0; r1 = r0 + 1;
+                            off0 = (int)((nx0 - 6) - ((took1 ? pbase1 : pbase0) + d0));
+                            off1 = (int)((nx1 - 6) - ((took1 ? pbase1 : pbase0) + d1));
+                        } else if (tid < 64) {                           // first hop: fetch its own 2 x 26 samples now
+                            const int gq = tid >> 5, i = tid & 31;
+                            if (i < 26) {
+                                const long gi = (gq ? nx1 : nx0) - 6 + i;
+                                rows[gq * CS_ROW + i] = (gi >= 0 && gi < len && (gq == 0 || g1ok)) ? dv_load(s, gi) : make_double2(0.0, 0.0);
+                            }
                         }
-                        const double fsnr = __shfl(v, found, 64);
-                        cur = nxt - max_offset + (found >= nt ? found - nt : found);
-                        if (lane == 0) {
-                            st->coarse_pos[n] = (double)((cur - 1) * dec + 1);
-                            st->coarse_snr[n] = fsnr;
+                        if (tid < 4 * CS_ROW) {
+                            // fetch what the next hop can ask for (plain loads, nothing waits on them in this hop):
+                            // rows (branch b, group g) start at nx_b + d_g - 11
+                            const int rr = tid / CS_ROW, i = tid - rr * CS_ROW;
+                            long gi = ((rr & 2) ? nx1 : nx0) - 11 + ((rr & 1) ? d1 : d0) + i;
+                            if (gi < 0 || gi >= len || ((rr & 2) && !g1ok)) gi = -1;
+                            pf = sraw[gi < 0 ? 0 : gi];
+                            pg = gi;
                         }
-                        ++n;
+                        pbase0 = nx0 - 11; pbase1 = nx1 - 11;
+                        have_pf = true;
                     }
+                    HOP_CYC(0);
+                    __syncthreads();                                     // rows of this hop are in LDS
+                    HOP_CYC(1);
+                    double v = -INFINITY, c_sig = 0.0, c_noise = 0.0;
+                    int found = -1;                                      // (wave 0) candidate the hop settles on, -1: none
+                    bool stop = false;
+                    for (int grp = 0; grp < 2; ++grp) {                  // +10-frame candidates, then (rarely) the +11-frame ones
+                        if (grp == 1 && !(sh_need1 && g1ok)) break;      // block-uniform
+                        if (fast) {
+                            if (tid < nt * 16) {                         // bin dk of window dw: direct 16-point DFT, four partial sums
+                                const cplx* x = rows + (grp ? r1 : r0) * CS_ROW + (grp ? off1 : off0) + dw;
+                                double pr_[4] = {0.0, 0.0, 0.0, 0.0}, pi_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                for (int m = 0; m < 16; ++m) {
+                                    const cplx t = tw[(dk * m) & 15], xv = x[m];
+                                    pr_[m & 3] = fma(xv.x, t.x, pr_[m & 3]); pi_[m & 3] = fma(xv.x, t.y, pi_[m & 3]);
+                                    pr_[m & 3] = fma(-xv.y, t.y, pr_[m & 3]); pi_[m & 3] = fma(xv.y, t.x, pi_[m & 3]);
+                                }
+                                const double xr = (pr_[0] + pr_[1]) + (pr_[2] + pr_[3]), xi = (pi_[0] + pi_[1]) + (pi_[2] + pi_[3]);
+                                Pb[dw * 17 + dk] = xr * xr + xi * xi;
+                            }
+                            HOP_CYC(2);
+                            __syncthreads();
+                        }
+                        if (tid < 64) {
+                            const bool cand = lane < nt;
+                            if (fast) {
+                                if (cand) {                              // candidate `lane` (move_fft_snr_runtime_avg.m:22-27)
+                                    double P[16];
+                                    const double* pr = Pb + lane * 17;
+#pragma unroll
+                                    for (int k = 0; k < 16; ++k) P[k] = pr[k];
+                                    // first maximum by a tree (ties: the lower index), total by a tree
+                                    double mv[8]; int mi[8];
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) { const bool r = P[2 * k + 1] > P[2 * k]; mv[k] = r ? P[2 * k + 1] : P[2 * k]; mi[k] = 2 * k + (r ? 1 : 0); }
+#pragma unroll
+                                    for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                                        for (int k = 0; k < w; ++k) { const bool r = mv[2 * k + 1] > mv[2 * k]; mv[k] = r ? mv[2 * k + 1] : mv[2 * k]; mi[k] = r ? mi[2 * k + 1] : mi[2 * k]; }
+                                    const double pc = mv[0], pm = pr[(mi[0] + 15) & 15], pp = pr[(mi[0] + 1) & 15];
+                                    double sig = pm + pc;
+                                    sig = sig + pp;
+                                    if (exact) {
+                                        double tot = 0.0;                // the reference's sequential sum(chn_tmp)
+#pragma unroll
+                                        for (int k = 0; k < 16; ++k) tot += P[k];
+                                        c_sig = sig; c_noise = tot - sig;
+                                        v = 10.0 * log10(c_sig / c_noise);
+                                    } else {                             // (the tree total differs from the sequential one by ~1e-16: inside eps)
+                                        double t8[8];
+#pragma unroll
+                                        for (int k = 0; k < 8; ++k) t8[k] = P[2 * k] + P[2 * k + 1];
+                                        c_sig = sig; c_noise = (((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]))) - sig;
+                                    }
+                                }
+                            } else if (cand) {
+                                v = window_snr_generic(s, (grp ? nx1 : nx0) - max_offset - 1 + lane, fft_len, tw);
+                            }
+                            bool is_hit, is_unc;
+                            if (ratio_mode) {
+                                const bool okn = c_noise > 0.0 && c_noise < INFINITY && c_sig < INFINITY;
+                                is_hit = cand && okn && c_sig > Rhi * c_noise;
+                                is_unc = cand && !(is_hit || (okn && c_sig < Rlo * c_noise));
+                            } else {
+                                is_hit = cand && (v - hit_avg_snr > th);     // NaN compares false
+                                is_unc = !exact && cand && !(fabs((v - hit_avg_snr) - th) > cert_delta);
+                            }
+                            const unsigned long long hm = __ballot(is_hit);
+                            if (!exact) {
+                                // every candidate the reference looks at (up to the first hit, else all of the group) must be
+                                // decided for good
+                                const unsigned long long unc = __ballot(is_unc);
+                                const unsigned long long looked = hm ? (2ull << (__ffsll((long long)hm) - 1)) - 1 : (1ull << nt) - 1;
+                                if (unc & looked) { if (lane == 0) { sh_redo = 1; sh_stop = 1; } stop = true; }
+                            }
+                            if (!stop) {
+                                if (hm) {
+                                    found = __ffsll((long long)hm) - 1;
+                                    const long nxt = grp ? nx1 : nx0;
+                                    const long ncur = nxt - max_offset + found;
+                                    if (lane == found) {
+                                        st->coarse_pos[n] = (double)((ncur - 1) * dec + 1);
+                                        if (ratio_mode) { hop_sig[2 * n] = c_sig; hop_sig[2 * n + 1] = c_noise; }
+                                        else st->coarse_snr[n] = v;
+                                        sh_cur = ncur; sh_took1 = grp; sh_need1 = 0;
+                                    }
+                                } else if (grp == 0 && g1ok) {           // :65 try across the idle frame
+                                    if (lane == 0) sh_need1 = 1;
+                                } else if (lane == 0) sh_stop = 1;       // :67 / both miss
+                            }
+                        }
+                        HOP_CYC(3);
+                        __syncthreads();
+                        if (sh_stop || !sh_need1) break;                 // block-uniform
+                    }
+                    if (sh_stop) break;
+                    cur = sh_cur;
+                    ++n;
+                    __syncthreads();                                     // (sh_* are rewritten by the next hop)
+                    HOP_CYC(4);
                 }
+#ifdef GSMCAL_DEVTIMING
+                if (g_stamps && tid == 0 && blockIdx.x < DEV_STAMP_BLOCKS) {
+                    unsigned long long* r = g_stamps + ((size_t)KID_COARSE_SCAN * DEV_STAMP_BLOCKS + blockIdx.x) * 16;
+                    unsigned long long acc = r[0];
+                    r[8] = acc;
+                    for (int i = 0; i < 5; ++i) { acc += cyc[i]; r[9 + i] = acc; }   // cumulative cycles per hop phase (report shows /100)
+                    r[14] = acc + 100ull * (unsigned long long)n;
+                }
+#endif
+                __syncthreads();
+                if (ratio_mode && tid >= 1 && tid < n)                   // the reported SNRs of hops 1..n-1 (:25)
+                    st->coarse_snr[tid] = 10.0 * log10(hop_sig[2 * tid] / hop_sig[2 * tid + 1]);
                 if (tid == 0) st->n_coarse = n;
-                CS_STAMP(3);
             }
         }
+        __syncthreads();
+        const int redo = sh_redo;
+        __syncthreads();
+        if (!redo) break;                                  // block-uniform
+        if (tid == 0) {                                    // start over with the exact replay
+            sh_exact = 1; sh_redo = 0; sh_hit = 0x7fffffff;
+            st->n_coarse = 0; st->coarse_hit_flag = 0; st->hit_avg_snr = INFINITY; st->mv_hit_idx = -1.0; st->mv_hit_snr = INFINITY;
+        }
+        n = 0;
+        __syncthreads();
+      }
+      CS_STAMP(4);
     } else if (!bad) {
         // ---- specific_fft_snr_fix_avg stand-alone ----
         const long lo = a.t_lo, hi = a.t_hi;
@@ -580,14 +714,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     __syncthreads();
     if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0);
     __syncthreads();
-    CS_STAMP(4);
+    CS_STAMP(5);
     {
         const uint4* src = (const uint4*)st;
         uint4* dst = (uint4*)st_g;
         for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
     }
-    CS_STAMP(5);
-    if (a.dbg && tid == 0) { a.dbg[blockIdx.x * 8 + 6] = (unsigned long long)sh_hit; a.dbg[blockIdx.x * 8 + 7] = (unsigned long long)n; }
+    CS_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -901,6 +1034,7 @@ __global__ void __launch_bounds__(FK_THREADS) k_fine_chunk(const cplx* __restric
     const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
     const int total = *n_items;
     fft37_tables(w37, wN2, N2, tid);
+    DEV_STAMP(KID_CHUNK, blockIdx.x, 0);
     for (int it = blockIdx.x; it < total; it += gridDim.x) {   // open (window, chunk) items, block-uniform
     const int item = items[it];
     const int c = item & 0xFF, widx = item >> 8, s = widx / H, w = widx - s * H;
@@ -998,6 +1132,7 @@ __global__ void __launch_bounds__(FK_THREADS) k_fine_chunk(const cplx* __restric
         r->E = E;
         r->count = sh_cnt <= FK_CAP ? sh_cnt : -1;
     }
+    DEV_STAMP(KID_CHUNK, blockIdx.x, 1 + (it / gridDim.x < 6 ? it / gridDim.x : 6));
     }
 }
 
@@ -1227,10 +1362,12 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 0);
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < wlen; i += nthr) xs[i] = x[i];
     if (tid == 0) { sh_a = 0; sh_b = nstep; }
     __syncthreads();
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 1);
     // ---- S: the tone's bin from a 148-point spectrum of the window's middle nfft samples summed in groups of
     // ov (nfft = 148*ov, so the two frequency grids coincide; the channel filter keeps the signal inside the
     // decimated band).  Only the choice of S depends on this estimate, never the result: a poor choice just
@@ -1298,6 +1435,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         __syncthreads();
     }
     const int lo = sh_lo;
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 2);
     const int j = tid & (FC_NB - 1), c = tid / FC_NB;
     const bool act = c < nchunk;                          // lanes beyond the last chunk only help with the shared phases
     const int k = ((lo + j) % nfft + nfft) % nfft;
@@ -1331,6 +1469,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         Sp[j * nM + m] = make_double2(ar, ai);
     }
     __syncthreads();
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 3);
     // ---- level 2: anchor X_k(64c) ----
     double xr = 0.0, xi = 0.0;
     if (act) {
@@ -1344,6 +1483,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         }
     }
     __syncthreads();                                      // S and the tables are dead: E and sumS take their place
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 4);
     // ---- E(t): E(0) by a block reduction, then a block scan of g[q] = |x[q+nfft]|^2 - |x[q]|^2 ----
     {
         double e0 = 0.0;
@@ -1379,6 +1519,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         }
         if (i1 == nstep && i0 < nstep) { Et[nstep] = run; Cs[nstep] = (float)rund; }
     }
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 5);
     // ---- slides: lane (c, j) walks chunk c of bin k; the 8 lanes of a group share the shift ----
     double best = -1.0;
     int bt = 0x7fffffff;
@@ -1423,6 +1564,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (op > best || (op == best && (ot < bt || (ot == bt && ok < bk)))) { best = op; bt = ot; bk = ok; }
     }
     __syncthreads();                                      // red_p was E(0) until here
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 6);
     if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
     __syncthreads();
     best = red_p[0]; bt = red_t[0]; bk = red_k[0];
@@ -1500,6 +1642,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             for (int i = 0; i < o.nch; ++i) items[base + i] = ((s * H + w) << 8) | i;
         }
     }
+    DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 7);
 }
 
 // The all-bins fp64 search (GSMCAL_PRESCREEN=0): kept as the ablation / cross-check of the two-pass scheme.

@@ -62,8 +62,7 @@ __device__ __forceinline__ PeakOut merge_peaks_coherent(const PeakOut* p, int NB
 // holds B[37][N2+1]; w37 | wN2 | P[2*hnl] follow the carve.  ~48 KB: three workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define BT_THREADS 512
-__device__ unsigned long long* g_bt_dbg = nullptr;   // development aid: per-phase timestamps of k_burst_tone
-#define BT_STAMP(i) do { if (g_bt_dbg && tid == 0) g_bt_dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#define BT_STAMP(i) DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, i)
 template <int GATE>
 __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, const GatherArgs& a, int nfft,
                                                 const cplx* __restrict__ tw_g, int ov, int prior_mode,
@@ -270,8 +269,10 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
                                                 const cplx* __restrict__ ts, int len_ts, int nshift,
                                                 unsigned char* smem) {
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 0);
     cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
     if (!xs) return;
+    DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 1);
     const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true);
     cplx* tc = (cplx*)(smem + gc.total);                                  // conj(ts), behind the gather carve
     cplx* part = tc + len_ts;                                             // nshift * SCH_PARTS partial sums
@@ -301,6 +302,7 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
         cv[o] = m * m;                      // :53 abs(...).^2
     }
     __syncthreads();
+    DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 2);
     if (tid < 64) {                                       // first maximum over the offsets: one wave, then a shuffle tree
         int mi = 0x7fffffff;
         double mx = -1.0;
@@ -455,7 +457,7 @@ __device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* c
 __device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl) {
     (void)s;
     st->sch_edge = 0;
-    st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0;
+    st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0; st->n_sent_rows = 1;   // :9 pos_info = [-1, -1]
     st->sampling_ppm2 = INFINITY; st->r2_kind = 0;
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
     if (st->status < 0) return;
@@ -481,7 +483,8 @@ __device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl) {
     st->n_win = 0;
     if (st->status < 0 || st->stage_status[1] != 0) return;
     st->n_sch_first = num_sch;
-    if (st->sch_edge) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63
+    if (st->sch_edge) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63 pos_info = [-1, -1]
+    st->n_sent_rows = 3 * st->n_fcch;                                          // :32 pos_info = -ones(3*num_fcch_hit, 2) from here on
     if (num_sch < 5) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }          // :84
     const double frame_ov = 1250.0 * (double)ov, slot_ov = 156.25 * (double)ov;
     const double d_ov = 10.0 * frame_ov, d1_ov = 11.0 * frame_ov;
@@ -613,7 +616,7 @@ __device__ void d_totals(const StreamState* st, int s, double* table, double* po
     row[GSMCAL_T_TOTAL_SAMPLING_PPM] = total_ppm(st->sampling_ppm1, st->sampling_ppm2);
     row[GSMCAL_T_TOTAL_CARRIER_PPM] = total_ppm(st->carrier_ppm1, st->carrier_ppm2);
     row[GSMCAL_T_N_FCCH] = st->fcch_is_sentinel ? 1.0 : (double)st->n_fcch;
-    row[GSMCAL_T_N_POS_ROWS] = st->n_rows == 0 ? 1.0 : (double)st->n_rows;
+    row[GSMCAL_T_N_POS_ROWS] = st->n_rows == 0 ? (double)(st->n_sent_rows > 0 ? st->n_sent_rows : 1) : (double)st->n_rows;
     row[GSMCAL_T_FIRST_FCCH_POS] = st->n_rows == 0 ? -1.0 : st->pos_info[0];
     row[GSMCAL_T_STATUS] = (double)st->status;
     if (pos_info_out) {
@@ -687,8 +690,10 @@ enum { STEP_FINE_SETUP = 1, STEP_FINE_DECIDE = 2, STEP_CARRIER_DECIDE = 4, STEP_
 // SCH stage's input level).  Called by every thread of a workgroup (>= 64 threads); `sh` is an LDS copy of the state.
 template <bool COHERENT>
 __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const StepArgs& a, int steps, int lvl_a,
-                                          int lvl_b, int s, StreamState* sh) {
+                                          int lvl_b, int s, StreamState* sh, int kid = -1) {
     const int lane = threadIdx.x;
+#define TAIL_STAMP(i) do { if (kid >= 0) DEV_STAMP(kid, blockIdx.y * gridDim.x + blockIdx.x, i); } while (0)
+    TAIL_STAMP(8);
     if (COHERENT) {       // inside the kernel that produced part of the state: read it past the caches
         const unsigned long long* src = (const unsigned long long*)(sts + s);
         unsigned long long* dst = (unsigned long long*)sh;
@@ -697,6 +702,7 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
         StateLds::load(sh, sts + s, lane);
     }
     __syncthreads();
+    TAIL_STAMP(9);
     if ((steps & STEP_FINE_DECIDE) && lane < sh->n_win && lane < MAXH) {
         // merge the NB partial peaks of window `lane` (the loads of all windows are in flight together)
         const PeakOut* pw = a.peaks + ((size_t)s * a.H + lane) * a.NB;
@@ -705,6 +711,7 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
         sh->prior_bin[lane] = pk.k;
     }
     if (steps & STEP_FINE_DECIDE) __syncthreads();
+    TAIL_STAMP(10);
     if (lane == 0) {
         if (steps & STEP_FINE_SETUP) d_fine_setup(sh, s, a.ov, lvl_a);
         if (steps & STEP_FINE_DECIDE) d_fine_decide(sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);
@@ -717,7 +724,10 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
         if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts);
     }
     __syncthreads();
+    TAIL_STAMP(11);
     if (!(steps == STEP_TOTALS || steps == STEP_SCAN_ACCEPT) && lane < 64) StateLds::store(sts + s, sh, lane);
+    TAIL_STAMP(12);
+#undef TAIL_STAMP
 }
 
 template <int STEPS>
@@ -738,7 +748,7 @@ struct TailArgs {
     StepArgs sa;
 };
 
-__device__ __forceinline__ void stream_tail(StreamState* __restrict__ sts, const TailArgs& t, unsigned char* smem) {
+__device__ __forceinline__ void stream_tail(StreamState* __restrict__ sts, const TailArgs& t, unsigned char* smem, int kid = -1) {
     if (!t.ctr) return;
     __shared__ int sh_last;
     // this workgroup's hand-over values were stored write-through (coherent_store); wait until they are acknowledged
@@ -752,7 +762,7 @@ __device__ __forceinline__ void stream_tail(StreamState* __restrict__ sts, const
     }
     __syncthreads();
     if (!sh_last) return;                                   // block-uniform
-    step_body<true>(sts, t.sa, t.steps, t.lvl_a, t.lvl_b, blockIdx.y, (StreamState*)smem);
+    step_body<true>(sts, t.sa, t.steps, t.lvl_a, t.lvl_b, blockIdx.y, (StreamState*)smem, kid);
 }
 
 template <int GATE>
@@ -761,14 +771,18 @@ k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft, const cplx* 
              TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     burst_tone_body<GATE>(sts, a, nfft, tw_g, ov, prior_mode, smem);
-    stream_tail(sts, tail, smem);
+    DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 5);
+    stream_tail(sts, tail, smem, GATE ? KID_BT1 : KID_BT0);
+    DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 6);
 }
 
 __global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
                                                     const cplx* __restrict__ ts, int len_ts, int nshift, TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     window_sch_body(sts, a, ts, len_ts, nshift, smem);
-    stream_tail(sts, tail, smem);
+    DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 3);
+    stream_tail(sts, tail, smem, KID_SCH);
+    DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 4);
 }
 
 __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
@@ -779,6 +793,9 @@ __global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restri
                                                      const FineCert* __restrict__ cert, int* __restrict__ n_open,
                                                      StreamState* __restrict__ sts_rw, TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 0);
     fine_verify_body(sts, win, win_stream_stride, win_stride, nshift, nfft, tw_g, rec, out, H, cert, n_open, smem);
-    stream_tail(sts_rw, tail, smem);
+    DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 1);
+    stream_tail(sts_rw, tail, smem, KID_VERIFY);
+    DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 2);
 }

@@ -702,5 +702,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
 
 __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
     (void)gather_core<256>(sts, a, smem, blockIdx.x, blockIdx.y, false);
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }

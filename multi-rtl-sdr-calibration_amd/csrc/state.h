@@ -9,6 +9,21 @@
 #include <stdint.h>
 #include "../../include/gsmcal.h"
 
+// Development build only (hipcc -DGSMCAL_DEVTIMING): per-phase timestamps inside the kernels.  The product library is
+// compiled without it and contains none of this.
+#ifdef GSMCAL_DEVTIMING
+__device__ unsigned long long* g_stamps = nullptr;   // [kernel id][DEV_STAMP_BLOCKS][16], 100 MHz wall clock
+#define DEV_STAMP_BLOCKS 1024
+#define DEV_STAMP(kid, blk, i)                                                                          \
+    do {                                                                                                \
+        if (g_stamps && threadIdx.x == 0 && (blk) < DEV_STAMP_BLOCKS)                                   \
+            g_stamps[((size_t)(kid) * DEV_STAMP_BLOCKS + (blk)) * 16 + (i)] = wall_clock64();          \
+    } while (0)
+#else
+#define DEV_STAMP(kid, blk, i) do { } while (0)
+#endif
+enum { KID_COARSE_SNR = 0, KID_COARSE_SCAN, KID_GATHER, KID_CERT, KID_CHUNK, KID_VERIFY, KID_BT1, KID_SCH, KID_BT0, KID_FRONT, KID_N };
+
 #define MAXH GSMCAL_MAX_HITS
 #define MAXROWS GSMCAL_MAX_POS_ROWS
 
@@ -65,6 +80,8 @@ struct alignas(16) StreamState {
     double sampling_ppm2;
     int r2_kind;             // r of SCH_corr_rate_correction: 0 = -1, 1 = s, 2 = resampled (or s when e==0)
     int n_rows;              // rows of pos_info (0 => sentinel)
+    int n_sent_rows;         // rows of the all -1 sentinel when n_rows == 0: 1 for pos_info = [-1 -1] (:9,:61), 3*num_fcch_hit
+                             // for the -ones(3K,2) pre-allocation returned by the :84 and :106-112 exits (:32)
     double pos_info[2 * MAXROWS];   // column-major, ld = MAXROWS
     // ---- post SCH ----
     double carrier_ppm2;
