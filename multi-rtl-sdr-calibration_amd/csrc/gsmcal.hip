@@ -339,8 +339,8 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         } else {
             LAUNCH(c, k_fine_openall, dim3(H, S), dim3(64), 0, (const StreamState*)st, nchunk, H, open_items, n_open);
         }
-        long nblk = (long)S * H * nchunk;                  // persistent blocks: three fit a CU
-        if (nblk > 3 * c->n_cu) nblk = 3 * c->n_cu;
+        long nblk = (long)S * H * nchunk;                  // persistent blocks: two of these 10-wave blocks are resident per CU
+        if (nblk > 2 * c->n_cu) nblk = 2 * c->n_cu;
         LAUNCH(c, k_fine_chunk, dim3((unsigned)nblk), dim3(FK_THREADS), fk_lds_bytes(g.nfft),
                (const cplx*)win, sstride, wstride, g.fine_nshift, g.nfft, (const cplx*)c->tw.p, certp,
                (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
@@ -348,7 +348,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         sa_fine.NB = 1;
         TailArgs tl;
         RET_IF(make_tail(c, S, sa_fine, STEP_FINE_DECIDE, lvl, 0, tl));
-        LAUNCH(c, k_fine_verify, dim3(H, S), dim3(256), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+        LAUNCH(c, k_fine_verify, dim3(H, S), dim3(FV_THREADS), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
                g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (const ChunkRec*)c->cur->chunkrec.p, peaks, H, certp, n_open,
                st, tl);
     } else {
@@ -463,7 +463,10 @@ static const auto k_front_fast47 = &k_front_fast<47, false>;
 static const auto k_front_fast31_sym = &k_front_fast<31, true>;
 static const auto k_front_fast31 = &k_front_fast<31, false>;
 
-static inline int lds_pad_host(int rel) { return rel + ((rel >> 6) << 3); }
+// instances of the coarse scan: 16-point windows with the latency / throughput register budgets, and any window length
+static const auto k_coarse_scan_lat = &k_coarse_scan<3, true>;   // (one register budget serves both: no spills at 165 registers)
+static const auto k_coarse_scan_thr = &k_coarse_scan<3, true>;
+static const auto k_coarse_scan_gen = &k_coarse_scan<2, false>;
 
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                 cplx* d_out, long out_stride) {
@@ -545,10 +548,12 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
-    LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), S), dim3(256), 0, a);
-    // two register budgets of the same kernel: small batches run one workgroup per CU anyway, big ones want four
-    if (S <= 512) LAUNCH(c, k_coarse_scan<2>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
-    else LAUNCH(c, k_coarse_scan<4>, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    const dim3 sgrid((unsigned)((nwin + 255) / 256), S);
+    if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, sgrid, dim3(256), 0, a); else LAUNCH(c, k_coarse_snr<false>, sgrid, dim3(256), 0, a);
+    // register budgets of the same kernel: small batches run one workgroup per CU anyway, big ones want four
+    if (fft_len != 16) LAUNCH(c, k_coarse_scan_gen, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    else if (S <= 512) LAUNCH(c, k_coarse_scan_lat, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    else LAUNCH(c, k_coarse_scan_thr, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     return 0;
 }
@@ -725,8 +730,9 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_front_fast47, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fast31_sym, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fast31, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_coarse_scan<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_coarse_scan<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan_thr, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -951,9 +957,11 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
     if (a.mode != 2 && nwin >= 1 && n_first <= len) {
         RET_IF(ensure(c, c->cur->snrbuf, (size_t)nwin * sizeof(double)));
         a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
-        LAUNCH(c, k_coarse_snr, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
+        if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
+        else LAUNCH(c, k_coarse_snr<false>, dim3((unsigned)((nwin + 255) / 256), 1), dim3(256), 0, a);
     }
-    LAUNCH(c, k_coarse_scan<2>, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    if (fft_len == 16) LAUNCH(c, k_coarse_scan_lat, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    else LAUNCH(c, k_coarse_scan_gen, dim3(1), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
     RET_IF(fetch_states(c, 1, v));
     *out = v[0];
@@ -1420,6 +1428,14 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
             }
         }
         if (!nb) continue;
+        if (k == KID_VERIFY) {
+            for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
+                const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];
+                if (!r[0] || !r[4]) continue;
+                fprintf(stderr, "verify block %d: items %llu open %llu | list %.1f anchors %.1f slides %.1f\n", b, (r[15] / 100ull) % 100000ull, r[15] / 10000000ull,
+                        (double)(r[3] - r[0]) / 100.0, (double)(r[4] - r[3]) / 100.0, (double)(r[5] - r[4]) / 100.0);
+            }
+        }
         std::vector<double> st0, en0;
         for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
             const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];

@@ -17,33 +17,30 @@
 #include "kernels_frontend.h"
 
 // ---- per-window SNR (move_fft_snr_runtime_avg.m:18-27) ------------------------------------------
-// 16-point FFT, radix-2 DIT, fully unrolled in registers (fp64).
+// 16-point FFT, radix-2 decimation in frequency, in place and fully unrolled in registers (fp64); the trivial
+// twiddles (1, -i) cost no multiplies.  The output is in BIT-REVERSED order: X[k] ends up in x[fft16_rev(k)].
+__device__ __forceinline__ constexpr int fft16_rev(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
 __device__ __forceinline__ void fft16(cplx* x) {
-    // bit reversal
-    const int rev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-    cplx y[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) y[i] = x[rev[i]];
     const double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178;  // cos/sin(pi/8)
     const double r2 = 0.70710678118654752440;
     const cplx w16[8] = {{1.0, 0.0}, {c1, -s1}, {r2, -r2}, {s1, -c1}, {0.0, -1.0}, {-s1, -c1}, {-r2, -r2}, {-c1, -s1}};
 #pragma unroll
-    for (int len = 2; len <= 16; len <<= 1) {
+    for (int len = 16; len >= 2; len >>= 1) {
         const int half = len >> 1, step = 16 / len;
 #pragma unroll
         for (int i = 0; i < 16; i += len) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const cplx w = w16[j * step];
-                const cplx u = y[i + j];
-                const cplx v = cmul(y[i + j + half], w);
-                y[i + j] = make_double2(u.x + v.x, u.y + v.y);
-                y[i + j + half] = make_double2(u.x - v.x, u.y - v.y);
+                const cplx u = x[i + j], v = x[i + j + half];
+                x[i + j] = make_double2(u.x + v.x, u.y + v.y);
+                const cplx d = make_double2(u.x - v.x, u.y - v.y);
+                const int t = j * step;
+                if (t == 0) x[i + j + half] = d;
+                else if (t == 4) x[i + j + half] = make_double2(d.y, -d.x);      // * (-i)
+                else x[i + j + half] = cmul(d, w16[t]);
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = y[i];
 }
 
 // SNR from the power spectrum P[0..L) (move_fft_snr_runtime_avg.m:22-27): first max, 3 circular bins
@@ -79,32 +76,29 @@ struct DecView {
     const double* head; // head[j] = sum_{k <= min(ntaps-1, decim*j)} coef[k], j < n_head: the rows whose filter()
     int n_head;         // window still overlaps the zero initial state (row 0 only when ntaps <= decim + 1)
 };
+// DC removal of a sample that was loaded raw
+__device__ __forceinline__ cplx dv_fix(const DecView& v, cplx x, long j) {
+    if (j < v.n_head) { const double h = v.head[j]; return make_double2(x.x - v.mr * h, x.y - v.mi * h); }
+    return make_double2(x.x - v.cr, x.y - v.ci);
+}
 __device__ __forceinline__ cplx dv_load(const DecView& v, long j) {
     const cplx x = v.s[j];
     if (j < v.n_head) { const double h = v.head[j]; return make_double2(x.x - v.mr * h, x.y - v.mi * h); }
     return make_double2(x.x - v.cr, x.y - v.ci);
 }
 
+// 16 samples from `start`.  The DC term of the batch path (DecView) is a constant over the window, and the DFT of a
+// constant lives in bin 0 alone, so it is removed there (X[0] -= 16 c) instead of from every sample.  NOT valid for
+// the few windows that still overlap filter()'s zero initial state (start < v.n_head): see window_snr_head.
 __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     cplx x[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = dv_load(v, start + i);
+    for (int i = 0; i < 16; ++i) x[i] = v.s[start + i];
     fft16(x);
+    x[0].x -= 16.0 * v.cr; x[0].y -= 16.0 * v.ci;
     double P[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) P[i] = x[i].x * x[i].x + x[i].y * x[i].y;   // abs(fft(.)).^2
-    return snr_from_power<16>(P);
-}
-
-// the same from 16 samples that are already loaded and DC-corrected (LDS or registers)
-__device__ __forceinline__ double window_snr16_buf(const cplx* b) {
-    cplx x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = b[i];
-    fft16(x);
-    double P[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) P[i] = x[i].x * x[i].x + x[i].y * x[i].y;
+    for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }   // abs(fft(.)).^2
     return snr_from_power<16>(P);
 }
 
@@ -140,14 +134,21 @@ __device__ __noinline__ double window_snr_generic(const DecView& s, long start, 
     return 10.0 * log10(sig / noise);
 }
 
-__device__ __forceinline__ double window_snr(const DecView& s, long start, int fft_len, const cplx* tw) {
-    return fft_len == 16 ? window_snr16(s, start) : window_snr_generic(s, start, fft_len, tw);
+// The windows that overlap filter()'s zero initial state (start < n_head; one per stream for the drivers' filters):
+// sample-by-sample DC removal; hx holds the corrected samples of the window.
+__device__ __forceinline__ double window_snr16_head(const cplx* hx) {
+    cplx x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = hx[i];
+    fft16(x);
+    double P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }
+    return snr_from_power<16>(P);
 }
 
-// DC removal of a sample that was loaded raw (the hop walk's look-ahead fetch): same arithmetic as dv_load
-__device__ __forceinline__ cplx dv_fix(const DecView& v, cplx x, long j) {
-    if (j < v.n_head) { const double h = v.head[j]; return make_double2(x.x - v.mr * h, x.y - v.mi * h); }
-    return make_double2(x.x - v.cr, x.y - v.ci);
+__device__ __forceinline__ double window_snr(const DecView& s, long start, int fft_len, const cplx* tw) {
+    return fft_len == 16 ? window_snr16(s, start) : window_snr_generic(s, start, fft_len, tw);
 }
 
 struct CoarseArgs {
@@ -224,12 +225,15 @@ __device__ __forceinline__ void coarse_twiddles(cplx* tw, int fft_len, int tid, 
 }
 
 // ---- k_coarse_snr: every sliding-window SNR of move_fft_snr_runtime_avg.m:17-28, all in parallel ----
-// grid (ceil(nwin/256), S), block 256.
-__global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
+// grid (ceil(nwin/256), S), block 256.  FFT16: the reference geometry (16-point windows, radix-2 in registers); the
+// other instance serves any window length 2..64 by direct DFTs (a called function: keeping it out of the FFT16
+// instance keeps that one free of scratch memory and within 128 registers -- four blocks per CU).
+template <bool FFT16>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_coarse_snr(CoarseArgs a) {
     __shared__ cplx tw[64];
     const CoarseGeom g = coarse_geom(a);
     if (g.fft_len > 64 || g.fft_len < 2 || g.n_first > a.len) return;   // the scan kernel reports the index error
-    coarse_twiddles(tw, g.fft_len, threadIdx.x, 256);
+    if (!FFT16) coarse_twiddles(tw, g.fft_len, threadIdx.x, 256);
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.nwin) return;
@@ -237,7 +241,16 @@ __global__ void __launch_bounds__(256) k_coarse_snr(CoarseArgs a) {
     if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }
     const DecView s = dec_view(a, blockIdx.y, mr, mi);
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = window_snr(s, i, g.fft_len, tw);
+    const double r = FFT16 ? window_snr16(s, i) : window_snr_generic(s, i, g.fft_len, tw);
+    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = r;
+    if (FFT16 && blockIdx.x == 0 && s.n_head > 0) {   // (block-uniform) redo the head windows with per-sample DC removal
+        __shared__ cplx hx[64 + 8];
+        const int nh = s.n_head < 8 ? s.n_head : 8;
+        if (threadIdx.x < nh + g.fft_len - 1 && threadIdx.x < g.n_first) hx[threadIdx.x] = dv_load(s, threadIdx.x);
+        __syncthreads();
+        if (threadIdx.x < nh && threadIdx.x < g.nwin)
+            a.snr_g[(size_t)blockIdx.y * a.snr_stride + threadIdx.x] = window_snr16_head(hx + threadIdx.x);
+    }
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
 
@@ -273,7 +286,7 @@ __host__ __device__ inline size_t coarse_scan_lds_fixed() {
     return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + 4 * CS_ROW * sizeof(cplx) + (2 * 11 * 17 + 2 * MAXH) * sizeof(double);
 }
 
-template <int WAVES>
+template <int WAVES, bool FFT16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     const int tid = threadIdx.x;
 #define CS_STAMP(i) DEV_STAMP(KID_COARSE_SCAN, blockIdx.x, i)
     CS_STAMP(0);
-    const bool bad = fft_len > 64 || fft_len < 2 || g.n_first > len;   // s(1:n_first): MATLAB index error
+    const bool bad = fft_len > 64 || fft_len < 2 || g.n_first > len || (FFT16 != (fft_len == 16));   // s(1:n_first): MATLAB index error
     // padded copy S = [999 x mv_len | snr[0..nwin) | 0 x 64]: S[q] is the SNR evicted by window q
     // (999 while the history still holds its seed, move_fft_snr_runtime_avg.m:11), S[mv_len+q] is
     // window q's own SNR; every load of the unrolled recurrence below is unconditional.  The global loads go out
@@ -508,7 +521,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 const double r_eps = 0.2303 * cert_delta + 1e-12;
                 const double Rhi = R * (1.0 + r_eps), Rlo = R * (1.0 - r_eps);
                 double* hop_sig = hop_sig_base;
-                const bool fast = fft_len == 16;
+                constexpr bool fast = FFT16;
                 const bool ratio_mode = !exact && fast;
                 // loader threads (tid < 4*CS_ROW): one look-ahead sample each; spectrum threads (tid < 11*16): one
                 // (window, bin) each; wave 0 lanes < 11 turn a group's powers into decisions
@@ -617,7 +630,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                                     }
                                 }
                             } else if (cand) {
-                                v = window_snr_generic(s, (grp ? nx1 : nx0) - max_offset - 1 + lane, fft_len, tw);
+                                if (!FFT16) v = window_snr_generic(s, (grp ? nx1 : nx0) - max_offset - 1 + lane, fft_len, tw);
                             }
                             bool is_hit, is_unc;
                             if (ratio_mode) {
@@ -697,7 +710,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
             } else {
                 const long cnt = hi - lo + 1;
-                for (long i = tid; i < cnt; i += 256) snr_s[i] = window_snr(s, lo - 1 + i, fft_len, tw);
+                for (long i = tid; i < cnt; i += 256) snr_s[i] = FFT16 ? window_snr16(s, lo - 1 + i) : window_snr_generic(s, lo - 1 + i, fft_len, tw);
                 __syncthreads();
                 if (tid == 0) {
                     for (long i = 0; i < cnt; ++i)
@@ -1014,7 +1027,7 @@ __host__ inline size_t fk_lds_bytes(int nfft) {
     const int N2 = nfft / 37;
     return ((size_t)nfft + FS_CHUNK + (size_t)37 * (N2 + 1) + 40 + N2) * sizeof(cplx) + FS_CHUNK * sizeof(float2);
 }
-__global__ void __launch_bounds__(FK_THREADS) k_fine_chunk(const cplx* __restrict__ win, long win_stream_stride,
+__global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_fine_chunk(const cplx* __restrict__ win, long win_stream_stride,
                                                           long win_stride, int nshift, int nfft,
                                                           const cplx* __restrict__ tw_g, const FineCert* __restrict__ cert,
                                                           ChunkRec* __restrict__ rec, int H,
@@ -1158,6 +1171,7 @@ __global__ void k_fine_openall(const StreamState* __restrict__ sts, int nchunk, 
 // LDS: the window | item anchors | item list.
 // ------------------------------------------------------------------------------------------------
 #define FV_MAX_ITEMS 512
+#define FV_THREADS 256
 // (agent-scope stores: the workgroup that runs the stream's decision step in this same kernel reads them)
 __device__ __forceinline__ void peak_store(PeakOut* dst, const PeakOut& o) {
     static_assert(sizeof(PeakOut) == 16, "two 64-bit words");
@@ -1179,8 +1193,8 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     cplx* anchor = xs + wlen;                             // X_k at the chunk's first shift, per item
     int* items = (int*)(anchor + FV_MAX_ITEMS);           // (k << 8) | chunk
     __shared__ int n_items, n_over;
-    __shared__ double red_p[4];
-    __shared__ int red_t[4], red_k[4];
+    __shared__ double red_p[FV_THREADS / 64];
+    __shared__ int red_t[FV_THREADS / 64], red_k[FV_THREADS / 64];
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1201,7 +1215,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     {
         const uint4* src = (const uint4*)(rec + ((size_t)s * H + w) * nchunk);
         uint4* dst = (uint4*)r;
-        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += 256) dst[i] = src[i];
+        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += FV_THREADS) dst[i] = src[i];
     }
     if (tid == 0) { n_items = 0; n_over = 0; }
     __syncthreads();
@@ -1212,7 +1226,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
         if (v > L) L = v;
     }
     L *= 1.0 - 1e-9;
-    for (int i = tid; i < nopen * FK_CAP; i += 256) {     // listed candidates of all open chunks
+    for (int i = tid; i < nopen * FK_CAP; i += FV_THREADS) {     // listed candidates of all open chunks
         const int c = i / FK_CAP, q = i - c * FK_CAP;
         const int cnt = r[c].count;
         if (cnt < 0) { if (q == 0) atomicAdd(&n_over, 1); continue; }
@@ -1225,12 +1239,13 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     }
     __syncthreads();
     const bool slow = n_over > 0 || n_items > FV_MAX_ITEMS;   // block-uniform; pathological inputs only (e.g. all zeros)
+    DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 3);
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     double best = -1.0;
     int bt = 0x7fffffff, bk = 0x7fffffff;
     if (tid == 0 && fc.p > 0.0) { best = fc.p; bt = fc.t; bk = fc.k; }   // the certificate's bins compete with the rest
     if (n_items > 0 || slow) {
-        for (int i = tid; i < wlen; i += 256) xs[i] = x[i];
+        for (int i = tid; i < wlen; i += FV_THREADS) xs[i] = x[i];
         __syncthreads();
         // normal case: one round over the listed items.  slow case: every (bin, open chunk) pair, FV_MAX_ITEMS at a time
         const long total = slow ? (long)nopen * nfft : (long)n_items;
@@ -1238,44 +1253,51 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
             const int ni = (int)(total - base < FV_MAX_ITEMS ? total - base : FV_MAX_ITEMS);
             if (slow) {
                 __syncthreads();
-                for (int i = tid; i < ni; i += 256) {
+                for (int i = tid; i < ni; i += FV_THREADS) {
                     const long g = base + i;
                     items[i] = ((int)(g % nfft) << 8) | (int)(g / nfft);
                 }
                 __syncthreads();
             }
-            // ---- anchors: wave-parallel direct DFT, item i handled by wave i % 4 ----
-            for (int i = wave; i < ni; i += 4) {
+            // ---- one wave per item: anchor X_k at the chunk's first shift by a wave-parallel direct DFT, then all 64
+            // shifts of the chunk at once.  Unrolling the recurrence, X_k(t0+m) = W^(-km) [X_k(t0) + S_m] with
+            // S_m = sum_{q<m} W^(kq) d_q, d_q = x[t0+q+nfft] - x[t0+q] (W = exp(-2 pi i/nfft)): a wave-wide prefix sum, and
+            // the rotation drops out of the power |X_k(t0) + S_m|^2.
+            for (int i = wave; i < ni; i += FV_THREADS / 64) {
                 const int k = items[i] >> 8, c = items[i] & 0xFF;
-                const cplx av = anchor_dft(xs + c * FS_CHUNK, k, tw_g, nfft, lane);
-                const double ar = av.x, ai = av.y;
-                if (lane == 0) anchor[i] = make_double2(ar, ai);
-            }
-            __syncthreads();
-            // ---- slides: one lane per item ----
-            for (int i = tid; i < ni; i += 256) {
-                const int k = items[i] >> 8, c = items[i] & 0xFF;
-                const cplx wk = tw_g[k];
-                const double wr = wk.x, wi = -wk.y;
-                double xr = anchor[i].x, xi = anchor[i].y;
                 const int t0 = c * FS_CHUNK;
-                if (c == 0) {                                    // the start window m = 0 belongs to chunk 0
-                    const double p = xr * xr + xi * xi;
-                    if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
-                }
+                const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
+                const double a0r = __shfl(av.x, 0, 64), a0i = __shfl(av.y, 0, 64);
                 const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
-                for (int j = 0; j < lim; ++j) {
-                    const cplx a = xs[t0 + j + nfft], b = xs[t0 + j];
-                    const double ar = xr + (a.x - b.x), ai = xi + (a.y - b.y);
-                    xr = ar * wr - ai * wi;
-                    xi = ar * wi + ai * wr;
+                double sr = 0.0, si = 0.0;
+                if (lane < lim) {
+                    const cplx xa = xs[t0 + lane + nfft], xb = xs[t0 + lane];
+                    const cplx t = tw_g[(int)(((long)k * lane) % nfft)];
+                    const double dr = xa.x - xb.x, di = xa.y - xb.y;
+                    sr = dr * t.x - di * t.y;
+                    si = dr * t.y + di * t.x;
+                }
+                for (int off = 1; off < 64; off <<= 1) {                 // inclusive scan: lane m ends with S_(m+1)
+                    const double orr = __shfl_up(sr, off, 64), oi = __shfl_up(si, off, 64);
+                    if (lane >= off) { sr += orr; si += oi; }
+                }
+                if (lane < lim) {
+                    const double xr = a0r + sr, xi = a0i + si;
                     const double p = xr * xr + xi * xi;
-                    const int m = t0 + j + 1;
+                    const int m = t0 + lane + 1;
                     if (p > best || (p == best && (m < bt || (m == bt && k < bk)))) { best = p; bt = m; bk = k; }
+                }
+                if (c == 0 && lane == 0) {                               // the start window m = 0 belongs to chunk 0
+                    const double p = a0r * a0r + a0i * a0i;
+                    if (p > best || (p == best && (0 < bt || (0 == bt && k < bk)))) { best = p; bt = 0; bk = k; }
                 }
             }
         }
     }
+    DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 5);
+#ifdef GSMCAL_DEVTIMING
+    if (g_stamps && tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < DEV_STAMP_BLOCKS) g_stamps[((size_t)KID_VERIFY * DEV_STAMP_BLOCKS + blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = (unsigned long long)n_items * 100ull + (unsigned long long)nopen * 10000000ull;
+#endif
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(best, off, 64);
         const int ot = __shfl_down(bt, off, 64);
@@ -1285,7 +1307,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < 4; ++i)
+        for (int i = 1; i < FV_THREADS / 64; ++i)
             if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
                 best = red_p[i]; bt = red_t[i]; bk = red_k[i];
             }

@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ st
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 4);
 }
 
-__global__ void __launch_bounds__(256) k_fine_verify(const StreamState* __restrict__ sts,
+__global__ void __launch_bounds__(FV_THREADS) k_fine_verify(const StreamState* __restrict__ sts,
                                                      const cplx* __restrict__ win, long win_stream_stride,
                                                      long win_stride, int nshift, int nfft,
                                                      const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
