@@ -414,8 +414,8 @@ def _oracle_one(args):
 
 def _pos_info(pos_t, table, i):
     k = int(table[i, 7])
-    if table[i, 8] == -1.0 and k == 1:
-        return np.array([[-1.0, -1.0]])
+    if table[i, 8] == -1.0:
+        return -np.ones((k, 2))
     return pos_t[i, :, :k].cpu().numpy().T.copy()
 
 

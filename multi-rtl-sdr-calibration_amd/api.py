@@ -359,8 +359,10 @@ def calibrate_batch(raw, coef, sch_training_sequence, carrier_freq, want_r=False
     rows = []
     for i in range(d):
         k = int(table[i, 7])
-        if table[i, 8] == -1.0 and k == 1:
-            rows.append(np.array([[-1.0, -1.0]]))
+        if table[i, 8] == -1.0:
+            # the reference's all -1 sentinel, in the shape of the exit taken: [-1 -1] (SCH_corr_rate_correction.m:9,:61) or
+            # the -ones(3*num_fcch_hit,2) pre-allocation of :32 returned by the :84 / :106-112 exits
+            rows.append(-np.ones((k, 2)))
         else:
             rows.append(pos_info[i, :, :k].T.copy())
     out["pos_info"] = rows

@@ -161,7 +161,7 @@ def test_chain_function_by_function(g, setup, dongle):
     parity.assert_positions(fp, o_fp, "FCCH_pos")
     parity.assert_ppm(sp1, o_sp1, "sampling_ppm(1)")
     parity.assert_ppm(cp1, o_cp1, "carrier_ppm(1)")
-    parity.assert_positions(pi, o_pi if not np.all(o_pi == -1) else np.array([[-1.0, -1.0]]), "pos_info")
+    parity.assert_positions(pi, o_pi, "pos_info")            # (sentinels included: [-1 -1] or -ones(3K,2), same shape)
     parity.assert_ppm(sp2, o_sp2, "sampling_ppm(2)")
     parity.assert_ppm(cp2, o_cp2, "carrier_ppm(2)")
     for got, want in ((r1, o_r1), (r2, o_r2), (r3, o_r3)):
@@ -194,7 +194,7 @@ def test_chain_at_other_oversampling_ratios(g, setup, ov):
         stream_close(r1, o_r1)
         o_pi, o_r2, o_sp2 = o.SCH_corr_rate_correction(o_r1, o_fp, ts, ov)
         pi, r2, sp2 = g.SCH_corr_rate_correction(r1, fp, ts, ov)
-        parity.assert_positions(pi, o_pi if not np.all(o_pi == -1) else np.array([[-1.0, -1.0]]), "pos_info")
+        parity.assert_positions(pi, o_pi, "pos_info")
         parity.assert_ppm(sp2, o_sp2, "sampling_ppm(2)")
         o_r3, o_cp2 = o.carrier_correct_post_SCH(o_r2, o_pi, ov, FC)
         r3, cp2 = g.carrier_correct_post_SCH(r2, pi, ov, FC)
@@ -237,9 +237,24 @@ def test_sch_and_post_sentinels(g, setup):
     shifted = o_fp + 200.0                                               # pushes the true peak outside the window
     want = o.SCH_corr_rate_correction(o_r1, shifted, ts, 8)
     got = g.SCH_corr_rate_correction(o_r1, shifted, ts, 8)
-    assert np.all(want[0] == -1) and np.all(got[0] == -1) and got[0].shape == (1, 2)
+    assert np.all(want[0] == -1) and np.all(got[0] == -1) and got[0].shape == want[0].shape == (1, 2)
     assert got[1] == -1.0 or isinstance(want[1], np.ndarray)
     parity.assert_ppm(got[2], want[2], "sampling ppm (edge)")
+    # spacing failure (SCH_corr_rate_correction.m:106-112): the reference hands back its -ones(3*num_fcch_hit, 2)
+    # pre-allocation (:32) and r = s (:87); gsm_sync_demod.m:130 counts those rows
+    bent = o_fp.copy()
+    bent[2:] += 300.0                                                    # the true peaks leave the search windows: interior maxima
+    want = o.SCH_corr_rate_correction(o_r1, bent, ts, 8)
+    got = g.SCH_corr_rate_correction(o_r1, bent, ts, 8)
+    assert want[0].shape == (3 * len(bent), 2) and np.all(want[0] == -1)
+    assert got[0].shape == want[0].shape and np.all(got[0] == -1)
+    assert isinstance(want[1], np.ndarray) and isinstance(got[1], np.ndarray) and len(got[1]) == len(want[1])
+    assert math.isinf(got[2]) and math.isinf(want[2])
+    # fewer than 5 SCH windows inside the stream (:84): same shape, r = -1
+    short = o_r1[: int(o_fp[4]) + 9000]                                  # the 5th SCH window runs out of samples
+    want = o.SCH_corr_rate_correction(short, o_fp[:5], ts, 8)
+    got = g.SCH_corr_rate_correction(short, o_fp[:5], ts, 8)
+    assert want[0].shape == (15, 2) and got[0].shape == (15, 2) and np.all(got[0] == -1) and got[1] == -1.0 and want[1] == -1.0
 
 
 # ---- batched hot path vs golden vectors and vs the oracle ---------------------------------------------
@@ -334,6 +349,53 @@ def test_too_short_capture_is_an_error_not_a_crash(g, setup):
         o.calibrate_stream(raw[0], setup["coef"], setup["ts"], FC)
 
 
+def test_scan_of_too_short_captures_is_an_index_error(g, setup):
+    # MATLAB stops at s(1:3594) (FCCH_coarse_position.m:25) when a capture has fewer than 23 frames: E_INDEX, not "no carrier"
+    raw = np.stack([g.synth.make_stream(dongle=0, num_frames=20)[0]])
+    with pytest.raises(g.GsmcalError, match="-5"):
+        g.fcch_scan_batch(raw, setup["coef30"])
+    with pytest.raises(o.MatlabIndexError):
+        o.scan_capture(raw[0], setup["coef30"])
+
+
+def test_repeated_batch_calls_on_the_default_stream(g, setup):
+    """gsmcal_ctx_create_on_stream(dev, 0): the legacy NULL stream cannot be captured into a hipGraph; repeated identical
+    calls must keep working (eager launches) and keep giving the same table."""
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in (0, 3)])
+    ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    c0 = g.Context(0, stream=0)
+    try:
+        for _ in range(4):
+            out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=c0)
+            assert np.array_equal(out["table"], ref["table"], equal_nan=True)
+        for _ in range(3):
+            sc = g.fcch_scan_batch(raw[:, : 2 * 640000], setup["coef30"], ctx=c0)
+        assert sc["num_hit"].shape == (2,)
+    finally:
+        c0.close()
+
+
+def test_long_filter_head_rows_are_dc_corrected_per_tap(g, setup):
+    """A 129-tap channel filter: the decimated rows 1 and 2 still overlap filter()'s zero initial state (64 j < 128), so
+    their DC term is mean * (partial tap sum), not mean * sum(coef).  The scanner path (FIR of the raw bytes + DC
+    removal on load) must agree with the oracle, which filters (raw - mean) like the reference."""
+    coef = g.synth.fir1(128, 200e3 / g.synth.FS)
+    caps = [g.synth.make_stream(dongle=80, arfcn=i, num_frames=64, bcch=True, start_frame=s0, frac_start=100.0)[0]
+            for i, s0 in enumerate((49, 0, 9))]                       # FCCH early in the capture: the first windows matter
+    raw = np.stack(caps)
+    out = g.fcch_scan_batch(raw, coef)
+    for i in range(len(caps)):
+        live = o.scan_capture(caps[i], coef)
+        n = out["counts"][i]
+        assert live["num_hit"] == out["num_hit"][i] and abs(live["snr"] - out["snr"][i]) < parity.SNR_ATOL
+        if live["coarse_pos"][0] != -1.0:
+            parity.assert_positions(out["positions"][i, :n], live["coarse_pos"], "positions (129 taps)")
+    # and the detector input itself: the first decimated rows of the front end
+    fe = g.frontend_batch(raw, coef, 64)
+    want = o.matlab_filter(coef, o.raw2iq(raw.T.astype(np.float64)))[0::64]
+    assert np.max(np.abs(fe.T[:8] - want[:8])) < 1e-11
+
+
 # ---- alternative code paths: every variant must give the oracle's answer ---------------------------------
 def test_front_end_variants_agree(g, setup, monkeypatch):
     """Register-row front kernel (symmetric / general taps) vs the generic LDS-tap kernel: same calibration."""
@@ -346,9 +408,13 @@ def test_front_end_variants_agree(g, setup, monkeypatch):
         det = g.last_batch_details(2)
         for i in range(2):
             parity.compare_stream(o.calibrate_stream(raw[i], coef, setup["ts"], FC), fast["table"][i], det, i, fast["pos_info"][i])
-        monkeypatch.setenv("GSMCAL_FRONT_GENERIC", "1")        # read at launch time
-        slow = g.calibrate_batch(raw, coef, setup["ts"], FC)
+        monkeypatch.setenv("GSMCAL_FRONT_GENERIC", "1")        # read when a context is created
+        other = g.Context(0)
         monkeypatch.delenv("GSMCAL_FRONT_GENERIC")
+        try:
+            slow = g.calibrate_batch(raw, coef, setup["ts"], FC, ctx=other)
+        finally:
+            other.close()
         assert np.array_equal(fast["table"][:, 6:], slow["table"][:, 6:])           # counts, status
         np.testing.assert_allclose(fast["table"][:, :6], slow["table"][:, :6], rtol=1e-9, atol=1e-12)
         assert all(np.array_equal(a, b) for a, b in zip(fast["pos_info"], slow["pos_info"]))
