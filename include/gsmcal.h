@@ -202,6 +202,14 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, lon
                                const double* carrier_freq, double* d_table, double* d_pos_info,
                                double* d_r_correct, long* d_r_len);
 
+/* Synthetic-input utility for benchmarks and tests (NOT part of the reference's path; SURVEY 8d: the 131 GB scanner
+ * configuration is generated on the device).  Expands k seeded base captures (d_base: [k][2n] bytes) into d distinct
+ * captures d_out: [d][2n]: capture first_unit+j = base[(first_unit+j) mod k] rotated by a per-capture number of
+ * samples, every byte dithered by -1/0/+1 from a counter-based hash of (seed, unit, sample), clipped to 0..255.
+ * multi-rtl-sdr-calibration_amd/synth.py:expand_capture() is the bit-identical host twin. */
+int gsmcal_synth_expand_dev(gsmcal_ctx* ctx, const uint8_t* d_base, int k, long n, uint8_t* d_out, long d,
+                            long first_unit, unsigned long long seed);
+
 /* Debug/parity taps into the last calibrate/scan batch: copies per-stream intermediates to host.
  * coarse_pos/coarse_snr/fine_first/fcch_pos/sch_first: [D][GSMCAL_MAX_HITS]; counts: [D][5]
  * (n_coarse, n_fine_first, n_fcch, n_sch_first, n_pos_rows).  Any pointer may be NULL. */

@@ -66,6 +66,8 @@ SIGNATURES = {
     "gsmcal_calibrate_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, c_double_p, C.c_int,
                                              c_double_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
+    "gsmcal_synth_expand_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_long, C.c_long,
+                                          C.c_ulonglong]),
     "gsmcal_last_batch_details": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
                                             c_double_p, c_int_p]),
 }

@@ -369,6 +369,25 @@ def calibrate_batch(raw, coef, sch_training_sequence, carrier_freq, want_r=False
     return out
 
 
+def fcch_scan_batch_dev(d_raw, d, n, coef, d_snr_numhit, d_positions=None, d_pos_snr=None, d_counts=None, ctx=None):
+    """Device-pointer form of fcch_scan_batch: only enqueues (call ctx.sync() before reading the outputs).
+    d_raw: [d][2n] bytes; d_snr_numhit: [d][2] doubles; optional [d][MAX_HITS] doubles x2 and [d] ints."""
+    ctx = ctx or default_context()
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    vp = lambda p: C.c_void_p(p) if p else None  # noqa: E731
+    ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(d_raw), int(d), int(n), _dp(coef), len(coef),
+                                                 C.c_void_p(d_snr_numhit), vp(d_positions), vp(d_pos_snr), vp(d_counts)),
+              "fcch_scan_batch_dev")
+
+
+def synth_expand_dev(d_base, k, n, d_out, d, first_unit=0, seed=20260101, ctx=None):
+    """Synthetic-input utility: expand k base captures on the device into d distinct ones (see include/gsmcal.h;
+    synth.expand_capture is the host twin)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.gsmcal_synth_expand_dev(ctx.h, C.c_void_p(d_base), int(k), int(n), C.c_void_p(d_out), int(d),
+                                              int(first_unit), int(seed)), "synth_expand_dev")
+
+
 def last_batch_details(d, ctx=None):
     """Intermediates of the last batch call (coarse/fine/SCH positions per stream) for parity tests."""
     ctx = ctx or default_context()

@@ -1358,6 +1358,23 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     return 0;
 }
 
+// ---- synthetic-input utility ---------------------------------------------------------------------------
+int gsmcal_synth_expand_dev(gsmcal_ctx* c, const uint8_t* d_base, int k, long n, uint8_t* d_out, long d, long first_unit,
+                            unsigned long long seed) {
+    if (!c || !d_base || !d_out || k < 1 || n < 1 || d < 1 || first_unit < 0) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->cur = &c->lanes[0];
+    for (long lo = 0; lo < d; lo += 32768) {            // grid.y limit
+        const long cnt = d - lo < 32768 ? d - lo : 32768;
+        long bx = (n / 8 + 255) / 256;
+        if (bx > 64) bx = 64;
+        LAUNCH(c, k_synth_expand, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, d_base, k, n, d_out + (size_t)lo * 2 * n,
+               first_unit + lo, seed);
+    }
+    CHECK_LAUNCH(c);
+    return 0;
+}
+
 int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* coarse_snr, double* fine_first,
                               double* fcch_pos, double* sch_first, int* counts) {
     if (!c || d < 1 || d > c->last_S) return GSMCAL_E_ARG;

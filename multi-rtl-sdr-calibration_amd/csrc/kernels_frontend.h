@@ -465,6 +465,57 @@ __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Synthetic-input utility (benchmarks and tests; not part of the reference's path): expand K seeded base captures
+// into D distinct captures on the device.  Capture u = base[u mod K] rotated by shift(u) samples, every I and Q
+// byte dithered by -1/0/+1 drawn from a counter-based hash of (seed, u, sample index), clipped to 0..255.  The
+// host twin (synth.expand_capture) produces the same bytes, so any capture of a 131 GB batch can be handed to
+// the CPU oracle without ever existing on the host.  grid (blocks, D), block 256; 8 samples (16 bytes) per lane-step.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned long long synth_mix64(unsigned long long x) {      // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline unsigned long long synth_shift(unsigned long long seed, unsigned long long unit, unsigned long long n) {
+    return synth_mix64(seed ^ (unit * 0xD1B54A32D192ED03ull)) % n;
+}
+__global__ void __launch_bounds__(256) k_synth_expand(const uint8_t* __restrict__ base, int K, long n,
+                                                       uint8_t* __restrict__ out, long first_unit,
+                                                       unsigned long long seed) {
+    const long u = first_unit + blockIdx.y;
+    const unsigned short* b = (const unsigned short*)(base + (size_t)(u % K) * 2 * n);
+    unsigned short* o = (unsigned short*)(out + (size_t)blockIdx.y * 2 * n);
+    const unsigned long long sh = synth_shift(seed, (unsigned long long)u, (unsigned long long)n);
+    const unsigned long long key = synth_mix64(seed + 0x632BE59BD9B4E019ull * (unsigned long long)u);
+    for (long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i0 < n; i0 += (long)gridDim.x * 256 * 8) {
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long i = i0 + j;
+            if (i >= n) { v[j] = 0; continue; }
+            long src = i + (long)sh;
+            if (src >= n) src -= n;
+            const unsigned smp = b[src];
+            const unsigned long long z = synth_mix64(key ^ (unsigned long long)i);
+            int I = (int)(smp & 0xFF) + (int)((z & 3) == 0) - (int)((z & 3) == 1);
+            int Q = (int)(smp >> 8) + (int)(((z >> 2) & 3) == 0) - (int)(((z >> 2) & 3) == 1);
+            I = I < 0 ? 0 : (I > 255 ? 255 : I);
+            Q = Q < 0 ? 0 : (Q > 255 ? 255 : Q);
+            v[j] = (unsigned short)(I | (Q << 8));
+        }
+        if (i0 + 8 <= n && (((uintptr_t)(o + i0)) & 15) == 0) {
+            uint4 w;
+            w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
+            w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+            *(uint4*)(o + i0) = w;
+        } else {
+            for (int j = 0; j < 8 && i0 + j < n; ++j) o[i0 + j] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // filter(coef,1,s) on a complex array, keeping rows 1:decim:end.  grid (ceil(nd/256), D).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fir_arr(const cplx* __restrict__ in, long in_stride, long n,

@@ -204,3 +204,38 @@ def make_stream(dongle=0, arfcn=0, num_frames=102, seed=DEFAULT_SEED, bcch=True,
     truth = {"sampling_ppm": eps_s, "carrier_ppm": eps_c, "snr_db": snr, "start_frame": sf,
              "frac_start": fs0, "carrier_freq": carrier_freq, "bcch": bcch}
     return raw, truth
+
+
+# ------------------------------------------------------------------------------------------------
+# Host twin of the device-side capture expansion (csrc/kernels_frontend.h: k_synth_expand).
+# ------------------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return x ^ (x >> np.uint64(31))
+
+
+def expand_capture(base, unit, seed=DEFAULT_SEED):
+    """Capture `unit` of gsmcal_synth_expand_dev(base, ...): base is (K, 2N) uint8.  Bit-identical to the device kernel."""
+    base = np.asarray(base, dtype=np.uint8)
+    k, two_n = base.shape
+    n = two_n // 2
+    with np.errstate(over="ignore"):
+        u = np.uint64(unit)
+        sh = int(_mix64(np.uint64(seed) ^ (u * np.uint64(0xD1B54A32D192ED03))) % np.uint64(n))
+        key = _mix64(np.uint64(seed) + np.uint64(0x632BE59BD9B4E019) * u)
+    b = base[int(unit) % k].reshape(n, 2)
+    src = (np.arange(n, dtype=np.int64) + sh) % n
+    z = _mix64(key ^ np.arange(n, dtype=np.uint64))
+    di = (z & np.uint64(3)).astype(np.int64)
+    dq = ((z >> np.uint64(2)) & np.uint64(3)).astype(np.int64)
+    out = np.empty((n, 2), dtype=np.int64)
+    out[:, 0] = b[src, 0].astype(np.int64) + (di == 0) - (di == 1)
+    out[:, 1] = b[src, 1].astype(np.int64) + (dq == 0) - (dq == 1)
+    return np.clip(out, 0, 255).astype(np.uint8).reshape(-1)

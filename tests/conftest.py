@@ -23,3 +23,8 @@ def gsmcal_mod():
 def ctx(gsmcal_mod):
     """A GPU context; fails loudly (never skips to a CPU path) when the HIP library or GPU is missing."""
     return gsmcal_mod.default_context(0)
+
+
+@pytest.fixture(scope="session")
+def g_mod(gsmcal_mod, ctx):
+    return gsmcal_mod

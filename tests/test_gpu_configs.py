@@ -1,0 +1,138 @@
+"""GPU tests at the sizes of BASELINE.json configs 3 and 5 (-m gpu).
+
+config 5: 256 dongles x 400 ARFCN over 8 GPUs = 12 800 captures x 640 000 IQ samples per GPU (16.4 GB of raw bytes,
+resident in HBM, generated on the device); config 3: 2 dongles x 100 ARFCN through the scanner's own bookkeeping
+(multi_rtl_sdr_gsm_FCCH_scanner.m:60-65 frequency split, :132-135 front end, :163-186 detect + accept, :206-207 record).
+The captures come from gsmcal_synth_expand_dev: a seeded set of synthetic GSM captures expanded on the device into
+distinct ones (rotation + counter-based dither); synth.expand_capture reproduces any of them bit for bit on the host,
+so sampled captures of the 16 GB batch go through the CPU oracle without the batch ever existing on the host."""
+import numpy as np
+import pytest
+
+import parity
+from oracle import gsmcal_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+FRAMES = 64                      # multi_rtl_sdr_gsm_FCCH_scanner.m:39
+N = FRAMES * 10000               # 640 000 complex samples per capture
+
+
+def _base_captures(g, k, dongle0):
+    """k seeded captures: three of four carry a BCCH carrier, a quarter of those at low SNR."""
+    caps = []
+    for i in range(k):
+        kw = {"bcch": i % 4 != 3}
+        if i % 8 == 1:
+            kw["snr_db"] = 4.0 + i % 5
+        caps.append(g.synth.make_stream(dongle=dongle0, arfcn=i, num_frames=FRAMES, **kw)[0])
+    return np.stack(caps)
+
+
+def _check_units(g, base, units, snr_numhit, positions, pos_snr, counts, coef, lo=0):
+    for u in units:
+        cap = g.synth.expand_capture(base, u)
+        live = o.scan_capture(cap, coef)
+        i = u - lo
+        assert live["num_hit"] == snr_numhit[i, 1], f"unit {u}: num_hit {snr_numhit[i, 1]} vs oracle {live['num_hit']}"
+        assert abs(live["snr"] - snr_numhit[i, 0]) < parity.SNR_ATOL, f"unit {u}: snr"
+        n = counts[i]
+        if live["coarse_pos"][0] == -1.0:
+            assert n == 0 and positions[i, 0] == -1.0
+        else:
+            parity.assert_positions(positions[i, :n], live["coarse_pos"], f"unit {u}: positions")
+            assert np.allclose(pos_snr[i, :n], live["coarse_snr"], rtol=0, atol=parity.SNR_ATOL)
+
+
+def test_config5_scanner_batch_12800_captures(g_mod, ctx):
+    g = g_mod
+    D, K = 12800, 32
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)                      # multi_rtl_sdr_gsm_FCCH_scanner.m:53
+    base = _base_captures(g, K, 5000)
+    H = g.MAX_HITS
+    d_base = ctx.alloc(base.nbytes)
+    d_raw = ctx.alloc(D * 2 * N)                                      # 16.4 GB
+    d_out = ctx.alloc(D * 2 * 8)
+    d_pos = ctx.alloc(D * H * 8)
+    d_psn = ctx.alloc(D * H * 8)
+    d_cnt = ctx.alloc(D * 4)
+    try:
+        ctx.h2d(d_base, base)
+        g.synth_expand_dev(d_base, K, N, d_raw, D, first_unit=0, ctx=ctx)
+        ctx.sync()
+        # the device generator and its host twin agree byte for byte (first, a middle and the last capture)
+        for u in (0, 7777, D - 1):
+            got = np.empty(2 * N, dtype=np.uint8)
+            ctx.d2h(got, d_raw + u * 2 * N)
+            assert np.array_equal(got, g.synth.expand_capture(base, u)), f"device capture {u} differs from the host twin"
+
+        def run(ptr, d, out_off=0):
+            g.fcch_scan_batch_dev(ptr, d, N, coef, d_out + out_off * 16, d_pos + out_off * H * 8, d_psn + out_off * H * 8,
+                                  d_cnt + out_off * 4, ctx=ctx)
+            ctx.sync()
+            sn = np.empty((d, 2)); ps = np.empty((d, H)); pn = np.empty((d, H)); cn = np.empty(d, dtype=np.int32)
+            ctx.d2h(sn, d_out + out_off * 16); ctx.d2h(ps, d_pos + out_off * H * 8)
+            ctx.d2h(pn, d_psn + out_off * H * 8); ctx.d2h(cn, d_cnt + out_off * 4)
+            return sn, ps, pn, cn
+
+        sn, ps, pn, cn = run(d_raw, D)
+        # (1) 64 sampled captures against the CPU oracle: num_hit and positions exact, snr within 1e-8 dB
+        rng = np.random.default_rng(5)
+        units = sorted(set([0, 1, D - 1] + [int(x) for x in rng.integers(0, D, 61)]))
+        _check_units(g, base, units, sn, ps, pn, cn, coef)
+        assert np.sum(sn[:, 1] > 0) > D // 4, "most BCCH captures should be accepted"
+        assert np.sum(sn[:, 1] == 0) > D // 8, "captures without a BCCH carrier must be rejected"
+        # (2) determinism: the same batch again (replayed as a hipGraph) gives the same bits
+        sn2, ps2, pn2, cn2 = run(d_raw, D)
+        assert np.array_equal(sn, sn2) and np.array_equal(ps, ps2) and np.array_equal(pn, pn2) and np.array_equal(cn, cn2)
+        # (3) units are independent: a sub-batch from the middle of the buffer (beyond 2^31 bytes) reproduces its rows
+        lo, cnt = 9000, 300
+        sn3, ps3, pn3, cn3 = run(d_raw + lo * 2 * N, cnt)
+        assert np.array_equal(sn3, sn[lo:lo + cnt]) and np.array_equal(ps3, ps[lo:lo + cnt]) and np.array_equal(cn3, cn[lo:lo + cnt])
+    finally:
+        for p in (d_base, d_raw, d_out, d_pos, d_psn, d_cnt):
+            ctx.free(p)
+
+
+def test_config3_two_dongle_100_arfcn_sweep(g_mod, ctx):
+    """multi_rtl_sdr_gsm_FCCH_scanner.m end to end for 2 dongles x 100 ARFCN: frequency plan (:60-65) -> 200 captures
+    -> detect + accept (:163-186) -> saved record (:206-207), every field against the oracle."""
+    g = g_mod
+    from gsmcal import dist as gd
+    num_dongle, start, step = 2, 935e6, 0.2e6
+    end = start + step * 198.5                                         # 199 points: padded to 200 = 2 x 100 (:62-65)
+    freq, num_pad = gd.scan_frequency_plan(start, end, step, num_dongle)
+    assert freq.shape == (2, 100) and num_pad == 1
+    D, K = freq.size, 20
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)
+    base = np.stack([g.synth.make_stream(dongle=6000, arfcn=i, num_frames=FRAMES, bcch=(i % 10 == 3 or i % 10 == 7))[0]
+                     for i in range(K)])                              # a fifth of the ARFCNs carry a BCCH carrier
+    d_base = ctx.alloc(base.nbytes)
+    d_raw = ctx.alloc(D * 2 * N)
+    try:
+        ctx.h2d(d_base, base)
+        g.synth_expand_dev(d_base, K, N, d_raw, D, first_unit=100000, ctx=ctx)
+        ctx.sync()
+        raw = np.empty((D, 2 * N), dtype=np.uint8)                    # unit i*100+j = (dongle i, sub-band point j), :69
+        ctx.d2h(raw, d_raw)
+    finally:
+        ctx.free(d_base); ctx.free(d_raw)
+    assert np.array_equal(raw[57], g.synth.expand_capture(base, 100057))
+    out = g.fcch_scan_batch(raw, coef, ctx=ctx)                       # host-pointer entry point, like the driver's loop
+    want_snr, want_hit = np.zeros(D), np.zeros(D)
+    for u in range(D):
+        live = o.scan_capture(raw[u], coef)
+        want_snr[u], want_hit[u] = live["snr"], live["num_hit"]
+        n = out["counts"][u]
+        if live["coarse_pos"][0] != -1.0:
+            parity.assert_positions(out["positions"][u, :n], live["coarse_pos"], f"unit {u}")
+    assert np.array_equal(out["num_hit"], want_hit)
+    assert np.max(np.abs(out["snr"] - want_snr)) < parity.SNR_ATOL
+    assert 20 <= np.sum(want_hit > 0) <= 60
+    rec = gd.scan_record(out["snr"], out["num_hit"], start, end, step, num_dongle, gain=0, num_samples=N,
+                         sampling_rate=g.synth.FS, coef=coef)
+    ref = gd.scan_record(want_snr, want_hit, start, end, step, num_dongle, gain=0, num_samples=N,
+                         sampling_rate=g.synth.FS, coef=coef)
+    for k in ("snr", "num_hit", "freq", "coef"):
+        assert np.allclose(rec[k], ref[k], rtol=0, atol=parity.SNR_ATOL)
+    assert rec["filename"] == ref["filename"] and rec["observe_time"] == N / g.synth.FS and rec["freq"].shape == (2, 100)
