@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msample/s through the FCCH+SCH calibration chain on MI355X.
 
-One step = one pass of the whole per-dongle body of gsm_sync_demod.m:107-124 (raw2iq -> channel
-filter -> FCCH_coarse_position -> FCCH_fine_correction -> SCH_corr_rate_correction ->
-carrier_correct_post_SCH -> total_ppm_calculation) over D synthetic dongle streams per GPU that are
-already resident in HBM, ending with the calibration table on the device (and, for N > 1, one RCCL
-all-gather of that table across ranks).  Msample/s = complex input samples of all ranks / wall time.
+One step = one pass of the whole per-dongle body of gsm_sync_demod.m:107-124 (raw2iq -> channel filter ->
+FCCH_coarse_position -> FCCH_fine_correction -> SCH_corr_rate_correction -> carrier_correct_post_SCH ->
+total_ppm_calculation) over D synthetic dongle streams per GPU that are already resident in HBM, ending with the
+calibration table ON THE HOST (an asynchronous device-to-host copy of the 80 B/stream table inside the step) and, for
+N > 1, one RCCL all-gather of that table across ranks.  Msample/s = complex input samples of all ranks / wall time
+(SURVEY.md 8d).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams D] [--mode table|stream]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams D] [--mode table|stream] [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The default run (N = 1) also times, inside the same process, the other BASELINE
+configurations as sub-results: config 2 (two streams), the same 64 streams with the corrected stream written
+(18 B/sample) and the scanner path at 200 and 12 800 captures (configs 3 / 5 per GPU).
 """
 from __future__ import annotations
 
@@ -30,9 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_PEAK_TFLOPS = 78.6       # MI355X fp64: vector peak == matrix (MFMA f64) peak
-FLOP_PER_BIN_STEP = 11       # sliding DFT: complex add (2) + complex multiply (6) + |X|^2 (3)
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # HBM bytes per launch from committed rocprofv3 --pmc passes
 
 
 def parse():
@@ -40,7 +41,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=64, help="dongle streams per GPU (weak scaling)")
+    ap.add_argument("--streams", type=int, default=64,
+                    help="dongle streams: per GPU with --scaling weak (default), in total with --scaling strong")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --streams per GPU (64/GPU: the driver's curve); strong: BASELINE config 4 as stated -- "
+                         "--streams in total, sharded block-contiguously over the ranks (64 -> 8 per GPU on 8 GPUs)")
     ap.add_argument("--frames", type=int, default=102, help="TDMA frames per stream (gsm_sync_demod.m:23)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic streams per GPU (tiled to --streams)")
     ap.add_argument("--mode", choices=["table", "stream"], default="table",
@@ -50,15 +55,55 @@ def parse():
                          "(front end + FCCH_coarse_position + acceptance; use --frames 64 --streams 200)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU-oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="no HIP events at all (otherwise the dominant kernel is bracketed inside the timed region and "
-                         "every kernel in a separate untimed pass)")
-    ap.add_argument("--no-config2", action="store_true", help="skip the extra two-stream (BASELINE config 2) latency measurement")
-    ap.add_argument("--dominant", default="k_front",
-                    help="kernel (name prefix) bracketed with HIP events inside the timed region: the front-end kernel "
-                         "is the one that moves the path's algorithmic bytes (every other kernel works on a few KB per "
-                         "burst and is bound by latency, not by HBM or the ALUs)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed HIP-event passes (roofline kernel figure, breakdown)")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub-results (config 2, stream mode, scanner path)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Calib:
+    """D streams resident in HBM + everything one calibration step needs."""
+
+    def __init__(self, torch, gsmcal, dev, ctx, raw_t, N, mode, coef, ts, fc):
+        self.torch, self.g, self.dev, self.ctx = torch, gsmcal, dev, ctx
+        self.raw_t, self.N, self.D = raw_t, N, raw_t.shape[0]
+        self.coef, self.ts = coef, ts
+        self.cf = np.full(self.D, fc)
+        D = self.D
+        self.table_t = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
+        self.rlen_t = torch.zeros((D,), dtype=torch.int64, device=dev)
+        self.r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if mode == "stream" else None
+        self.host_table = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)]
+        dp = gsmcal._lib.c_double_p
+        self._p = (coef.ctypes.data_as(dp), ts.ctypes.data_as(dp), self.cf.ctypes.data_as(dp))
+
+    def launch(self, b=0, d=None):
+        """enqueue one calibration pass over the first d streams into table buffer b"""
+        ctx, lib = self.ctx, self.ctx.lib
+        cp, tp, fp = self._p
+        rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(self.raw_t.data_ptr()), self.D if d is None else d, self.N,
+                                            cp, len(self.coef), tp, len(self.ts), fp,
+                                            C.c_void_p(self.table_t[b].data_ptr()), C.c_void_p(self.pos_t.data_ptr()),
+                                            C.c_void_p(self.r_t.data_ptr()) if self.r_t is not None else None,
+                                            C.c_void_p(self.rlen_t.data_ptr()))
+        ctx.check(rc, "gsmcal_calibrate_batch_dev")
+
+    def to_host(self, b=0):
+        """the step ends with the table on the host: asynchronous copy on the same stream (pinned destination)"""
+        self.host_table[b].copy_(self.table_t[b], non_blocking=True)
+
+
+def time_steps(torch, dev, fn, steps, warmup, fence=None):
+    fence = fence or (lambda: torch.cuda.synchronize(dev))
+    for _ in range(warmup):
+        fn()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -66,13 +111,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     import torch
     import torch.distributed as dist
 
     import gsmcal
+    from gsmcal import dist as gdist
     from gsmcal import synth
 
     torch.cuda.set_device(local_rank)
@@ -86,39 +131,43 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "scan":
-        return bench_scan(args, rank, world, dev, use_dist)
-    D, frames = args.streams, args.frames
+        return bench_scan_main(args, rank, world, dev, use_dist)
+    frames = args.frames
     N = frames * synth.FRAME_OV
     fc = 957.4e6                                            # gsm_sync_demod.m:14
     coef = np.ascontiguousarray(synth.fir1(46, 200e3 / synth.FS))   # gsm_sync_demod.m:34
     ts = np.ascontiguousarray(synth.sch_training_sequence())
-    cf = np.full(D, fc)
+    # units of this rank: weak scaling = --streams per GPU; strong = --streams in total, block-contiguous shards
+    if args.scaling == "strong":
+        total_units = args.streams
+        lo, hi = gdist.shard_range(total_units, world, rank)
+    else:
+        total_units = args.streams * world
+        lo, hi = rank * args.streams, (rank + 1) * args.streams
+    D = hi - lo
+    if D < 1:
+        raise SystemExit("more ranks than streams")
+    sizes = gdist.shard_sizes(total_units, world) if args.scaling == "strong" else [args.streams] * world
+    Dmax = max(sizes)
 
-    # ---- synthetic input, resident in HBM before the timed region ----
+    # ---- synthetic input, resident in HBM before the timed region (unit u = global stream index) ----
     nd = max(1, min(args.distinct, D))
-    distinct = np.stack([synth.make_stream(dongle=rank * D + i, num_frames=frames)[0] for i in range(nd)])
+    distinct = np.stack([synth.make_stream(dongle=lo + i, num_frames=frames)[0] for i in range(nd)])
     raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device
-    table_t = torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev)
-    pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
-    rlen_t = torch.zeros((D,), dtype=torch.int64, device=dev)
-    r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if args.mode == "stream" else None
-    gathered = torch.zeros((world * D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) if use_dist else None
 
-    # a dedicated (non-default) stream: the library forks its internal lanes off this stream, and torch's
+    # a dedicated (non-default) stream: the library forks its internal lanes off this stream, and torch's copies and
     # collectives are enqueued on it too, so one synchronize covers the whole step
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
-    lib = ctx.lib
-    dp = gsmcal._lib.c_double_p
-    coef_p, ts_p, cf_p = coef.ctypes.data_as(dp), ts.ctypes.data_as(dp), cf.ctypes.data_as(dp)
+    cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc)
 
     # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
-    # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written on its own stream, and
-    # the only wait is before a buffer is written again two steps later (a GPU-side stream wait, the host never
-    # blocks).  The timed region ends with both collectives waited for.
-    tables = [table_t, torch.zeros_like(table_t)] if use_dist else [table_t]
-    gath2 = [gathered, torch.zeros_like(gathered)] if use_dist else None
+    # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written, and the only wait is
+    # before a buffer is written again two steps later.  Uneven shards (strong scaling) are padded to the largest.
+    gath = [torch.zeros((world * Dmax, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    send = [torch.full((Dmax, gsmcal.TABLE_COLS), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    host_gath = [torch.zeros((world * Dmax, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     works = [None, None]
     nstep = [0]
 
@@ -127,146 +176,104 @@ def main():
         nstep[0] += 1
         if use_dist and works[b] is not None:
             works[b].wait()
-        rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, coef_p, len(coef), ts_p,
-                                            len(ts), cf_p, C.c_void_p(tables[b].data_ptr()),
-                                            C.c_void_p(pos_t.data_ptr()),
-                                            C.c_void_p(r_t.data_ptr()) if r_t is not None else None,
-                                            C.c_void_p(rlen_t.data_ptr()))
-        ctx.check(rc, "gsmcal_calibrate_batch_dev")
+        cal.launch(b)
         if use_dist:
-            # one RCCL all-gather of the per-dongle ppm table
-            works[b] = dist.all_gather_into_tensor(gath2[b], tables[b], async_op=True)
+            src = cal.table_t[b]
+            if D != Dmax:
+                send[b][:D].copy_(src)
+                src = send[b]
+            works[b] = dist.all_gather_into_tensor(gath[b], src, async_op=True)    # one RCCL all-gather of the ppm table
+        else:
+            cal.to_host(b)
 
     def fence():
         for b in range(2):
             if works[b] is not None:
                 works[b].wait()
                 works[b] = None
+                host_gath[b].copy_(gath[b], non_blocking=True)      # gathered table to the host (every rank)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_events = not args.no_kernel_events
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    # ---- HIP-event passes (rank 0).  Timing events cannot ride in the region above without distorting it: as soon
-    # as one dispatch carries start/stop events this runtime switches the queue to profiled dispatch, and the whole
-    # step slows by ~13 % (0.34 -> 0.39 ms).  So the same K steps are run again, first with events on the front-end
-    # kernel only (the roofline figure), then on every kernel (the breakdown).
-    prof_dom, prof = {}, {}
-    if kernel_events and rank == 0:
-        for filt, store in ((args.dominant, prof_dom), (None, prof)):
-            ctx.profile_reset()
-            ctx.profile_filter(filt)
-            ctx.profile_enable(True)
-            for _ in range(args.steps):
-                ctx.check(lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, coef_p, len(coef), ts_p,
-                                                         len(ts), cf_p, C.c_void_p(table_t.data_ptr()),
-                                                         C.c_void_p(pos_t.data_ptr()),
-                                                         C.c_void_p(r_t.data_ptr()) if r_t is not None else None,
-                                                         C.c_void_p(rlen_t.data_ptr())), "gsmcal_calibrate_batch_dev")
-            torch.cuda.synchronize(dev)
-            store.update(ctx.profile_get())
-            ctx.profile_enable(False)
-    # BASELINE config 2 (gsm_sync_demod.m on 2 dongle streams): the same call on the first two streams, for the record
-    cfg2 = None
-    if rank == 0 and D >= 2 and args.mode == "table" and not use_dist and not args.no_config2:
-        def two():
-            ctx.check(lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), 2, N, coef_p, len(coef), ts_p, len(ts),
-                                                     cf_p, C.c_void_p(table_t.data_ptr()), C.c_void_p(pos_t.data_ptr()), None,
-                                                     C.c_void_p(rlen_t.data_ptr())), "gsmcal_calibrate_batch_dev")
-        for _ in range(3):
-            two()
-        torch.cuda.synchronize(dev)
-        c0 = time.perf_counter()
-        for _ in range(args.steps):
-            two()
-        torch.cuda.synchronize(dev)
-        t2 = (time.perf_counter() - c0) / args.steps
-        cfg2 = {"streams": 2, "ms_per_call": round(1e3 * t2, 4), "Msample_per_s": round(2 * N / t2 / 1e6, 1)}
-        step()                                  # restore the full batch's outputs and lane bookkeeping
-        torch.cuda.synchronize(dev)
-    if use_dist:
-        fence()
+    elapsed = time_steps(torch, dev, step, args.steps, args.warmup, fence)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    last = ((nstep[0] - 1) & 1) if use_dist else 0
+    table = (cal.host_table[last] if not use_dist else cal.table_t[last].cpu()).numpy().copy()
 
-    # ---- results of the last step ----
-    table = tables[(nstep[0] - 1) & 1 if use_dist else 0].cpu().numpy()
+    # ---- every rank checks rows of its OWN shard against the CPU oracle before anything is reported ----
+    from oracle import gsmcal_oracle as oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
     det = gsmcal.last_batch_details(min(D, nd), ctx=ctx)
-    n_ok = int(np.sum(table[:, 9] == 0))
-    total_samples = world * D * N * args.steps
-    value = total_samples / elapsed / 1e6
+    pos_host = cal.pos_t.cpu().numpy()
+    n_rank_checked = 0
+    for i in ([0] if world > 1 else []):
+        parity.compare_stream(oracle.calibrate_stream(distinct[i], coef, ts, fc), table[i], det, i, _pos_info(pos_host, table, i))
+        n_rank_checked += 1
+    if use_dist:
+        g = host_gath[last].numpy()
+        off = rank * Dmax
+        assert np.array_equal(g[off:off + D], table, equal_nan=True), "all-gathered table differs from this rank's rows"
 
+    n_ok = int(np.sum(table[:, 9] == 0))
+    total_samples = sum(sizes) * N * args.steps
+    value = total_samples / elapsed / 1e6
+    bps = 2 if args.mode == "table" else 18
     out = {
         "metric": "IQ Msamples/s through FCCH+SCH calib",
         "value": round(value, 3), "unit": "Msample/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64",
         "data": f"synthetic 8x-oversampled GSM BCCH-carrier uint8 IQ (seed {synth.DEFAULT_SEED}); {nd} distinct "
                 f"streams per GPU tiled to {D}",
-        "config": {"workload": f"cfg4-style full chain gsm_sync_demod.m:107-124: {D} dongle streams/GPU x {N} IQ samples "
-                               f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation",
-                   "streams_per_gpu": D, "samples_per_stream": N, "output": args.mode,
-                   "bytes_per_sample_algorithmic": 2 if args.mode == "table" else 18,
+        "config": {"workload": f"cfg4 full chain gsm_sync_demod.m:107-124: {sum(sizes)} dongle streams ({Dmax}/GPU) x {N} IQ samples "
+                               f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation, table on the host",
+                   "streams_per_gpu": Dmax, "streams_total": sum(sizes), "samples_per_stream": N, "output": args.mode,
+                   "bytes_per_sample_algorithmic": bps,
                    "collective": "all_gather(table) over RCCL" if use_dist else "none",
-                   "streams_calibrated_ok": n_ok},
+                   "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked},
     }
-    if cfg2:
-        out["baseline_config2_two_streams"] = cfg2
-
     if rank == 0:
-        # ---- roofline (HIP events on the launch streams, inside the timed region) ----
-        # The chain reads every raw byte exactly once, in the front-end kernel; all later kernels touch a few KB per
-        # burst.  The HBM roofline of the path (north_star: "fraction of HBM roofline") is therefore that kernel's.
-        if prof:
-            tot = {k: v[0] for k, v in prof.items()}
-            dom = max(tot, key=tot.get)
-            out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / args.steps, 4)
-                                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-            front = [k for k in prof_dom if k.startswith("k_front") and prof_dom[k][1]] or \
-                    [k for k in prof if k.startswith("k_front") and prof[k][1]]
-            traffic = {}
-            if os.path.exists(PMC_FILE):
-                with open(PMC_FILE) as f:
-                    pmc = json.load(f)
-                # (the PMC pass ran the default configuration: one launch over all D streams)
-                if pmc.get("streams_per_gpu") == D and pmc.get("samples_per_stream") == N and D < 128:
-                    traffic = pmc.get("hbm_bytes_per_launch", {})
-            if front:
-                k = front[0]
-                tot_ms, launches = prof_dom[k] if k in prof_dom and prof_dom[k][1] else prof[k]
-                avg = tot_ms / launches
-                per_launch = D * N * 2.25 * args.steps / launches        # the batch is split over the library's lanes
-                ach = per_launch / 1e9 / (avg * 1e-3)
-                out["roofline"] = {"kernel": k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                   "traffic": next((v for kk, v in traffic.items() if kk.startswith("k_front")), None),
-                                   "avg_launch_ms": round(avg, 5), "launches_per_step": launches // args.steps,
-                                   "algorithmic_bytes_per_launch": int(per_launch),
-                                   "timed_with": "HIP events on the kernel's own dispatch (hipExtLaunchKernel start/stop), "
-                                                 "second run of the same K steps right after the timed region",
-                                   "note": "2 B/sample raw read + 16/64 B/sample decimated complex-double write; the "
-                                           "only kernel of the chain that streams from HBM (launches of the "
-                                           "library's concurrent lanes overlap other kernels)"}
-            out["time_dominant_kernel"] = {"kernel": dom, "ms_per_step": round(tot[dom] / args.steps, 4),
-                                           "note": "largest single kernel by time; the per-burst kernels are serial "
-                                                   "fp64 decision chains bound by instruction latency (DESIGN.md section 4)"}
+        path_gbs = value * 1e6 * bps / 1e9
+        roof = {"bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(path_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "what": f"WHOLE PATH (SURVEY 8d): Msample/s x {bps} B/sample; every raw byte is read once, by the front-end "
+                        "kernel; the rest of the chain works on a few KB per burst and is latency-bound (DESIGN.md 4)"}
+        # ---- HIP-event passes (untimed): the same K steps again with events on every kernel ----
+        if not args.no_kernel_events:
+            prof = event_pass(ctx, lambda: cal.launch(0), args.steps, torch, dev)
+            if prof:
+                tot = {k: v[0] for k, v in prof.items()}
+                dom = max(tot, key=tot.get)
+                out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / args.steps, 4)
+                                                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+                front = [k for k in prof if k.startswith("k_front") and prof[k][1]]
+                if front:
+                    k = front[0]
+                    tot_ms, launches = prof[k]
+                    avg = tot_ms / launches
+                    per_launch = D * N * 2.25 * args.steps / launches        # the batch may be split over the library's lanes
+                    ach = per_launch / 1e9 / (avg * 1e-3)
+                    traffic, src = pmc_traffic(k, D, N)
+                    roof["kernel"] = {"name": k, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                      "avg_launch_ms": round(avg, 5), "launches_per_step": launches // args.steps,
+                                      "algorithmic_bytes_per_launch": int(per_launch),
+                                      "share_of_step_time": round(tot[k] / sum(tot.values()), 3),
+                                      "traffic": traffic, "traffic_source": src,
+                                      "what": "the one HBM-streaming kernel: 2 B/sample raw read + 16/64 B/sample decimated write; "
+                                              "HIP events on its own dispatch, second run of the same K steps"}
+                roof["time_dominant_kernel"] = {"name": dom, "ms_per_step": round(tot[dom] / args.steps, 4),
+                                                "bound": "latency (serial fp64 dependency chains, one to three workgroups per CU)"}
+        out["roofline"] = roof
+        if world == 1 and not args.no_sub:
+            out["sub_results"] = sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream)
         # ---- CPU baseline: the oracle (fp64 NumPy/SciPy restatement) on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import gsmcal_oracle as oracle
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import parity
             done, t_cpu, checked = 0, 0.0, 0
             while t_cpu < args.cpu_seconds and done < 64:
                 i = done % nd
@@ -275,7 +282,7 @@ def main():
                 t_cpu += time.perf_counter() - c0
                 done += 1
                 if done <= nd:      # checker: the GPU result of this very stream must match the oracle
-                    parity.compare_stream(orc, table[i], det, i, _pos_info(pos_t, table, i))
+                    parity.compare_stream(orc, table[i], det, i, _pos_info(pos_host, table, i))
                     checked += 1
             out["cpu_baseline"] = {"value": round(done * N / t_cpu / 1e6, 4), "unit": "Msample/s", "cores": 1,
                                    "kind": "port",
@@ -300,31 +307,101 @@ def main():
                 out["speedup_vs_cpu_all_cores"] = round(value / out["cpu_baseline_all_cores"]["value"], 1)
         print(json.dumps(out))
     if use_dist:
-        if rank == 0 and gathered is not None:
-            last = (nstep[0] - 1) & 1
-            assert torch.equal(gath2[last][:D], tables[last]), "all-gathered table differs from the local rows"
         dist.destroy_process_group()
 
 
-def bench_scan(args, rank, world, dev, use_dist):
-    """Scanner path (BASELINE configs 3/5): D captures resident in HBM -> snr, num_hit per capture."""
-    import torch
+def event_pass(ctx, fn, steps, torch, dev, filt=None):
+    """K more steps with HIP events attached to every kernel dispatch.  They cannot ride in the timed region: as soon as
+    one dispatch carries start/stop events this runtime switches the queue to profiled dispatch and the whole step
+    slows by ~13 %."""
+    ctx.profile_reset()
+    ctx.profile_filter(filt)
+    ctx.profile_enable(True)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    prof = dict(ctx.profile_get())
+    ctx.profile_enable(False)
+    return {k: v for k, v in prof.items() if v[1]}
+
+
+def pmc_traffic(kernel, D, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  NOT measured in this run."""
+    if not os.path.exists(PMC_FILE):
+        return None, "no committed PMC pass for this configuration"
+    with open(PMC_FILE) as f:
+        pmc = json.load(f)
+    if pmc.get("streams_per_gpu") != D or pmc.get("samples_per_stream") != N:
+        return None, "committed PMC pass is for another batch shape"
+    for k, v in pmc.get("hbm_bytes_per_launch", {}).items():
+        if k.startswith(kernel[:12]):
+            return v, "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+    return None, "kernel not in the committed PMC pass"
+
+
+def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream):
+    """The other BASELINE configurations, timed in this same (driver-run) process."""
+    from gsmcal import synth
+    sub = {}
+    K, W = args.steps, max(2, args.warmup)
+    # config 2: gsm_sync_demod.m on 2 dongle streams (latency-bound)
+    if cal.D >= 2 and args.mode == "table":
+        def two():
+            cal.launch(0, 2)
+            cal.to_host(0)
+        t = time_steps(torch, dev, two, K, W) / K
+        sub["config2_two_streams"] = {"streams": 2, "ms_per_call": round(1e3 * t, 4), "Msample_per_s": round(2 * N / t / 1e6, 1)}
+        cal.launch(0)
+        torch.cuda.synchronize(dev)
+    # the same streams with the corrected stream written (the API's real output, 18 B/sample)
+    if args.mode == "table":
+        cs = Calib(torch, gsmcal, dev, ctx, cal.raw_t, N, "stream", coef, ts, fc)
+
+        def st():
+            cs.launch(0)
+            cs.to_host(0)
+        t = time_steps(torch, dev, st, max(3, K // 4), 2) / max(3, K // 4)
+        v = cal.D * N / t / 1e6
+        sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
+                              "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
+                              "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4)}
+        assert torch.equal(cs.table_t[0], cal.table_t[0]) or bool(torch.allclose(cs.table_t[0], cal.table_t[0], equal_nan=True))
+        del cs
+        torch.cuda.empty_cache()
+    # scanner path: BASELINE config 3 (200 captures) and config 5 per GPU (12 800 captures, 16.4 GB, generated on the device)
+    for name, ncap in (("config3_scan_200", 200), ("config5_scan_12800_per_gpu", 12800)):
+        try:
+            r = bench_scan(args, torch, gsmcal, dev, ctx, ncap, 64, distinct=32, steps=max(5, K // 2), warmup=2, cpu=False)
+            sub[name] = {k: r[k] for k in ("ms_per_step", "value", "hbm_GBps_algorithmic", "path_frac_of_hbm", "captures_with_hits",
+                                           "kernels_ms_per_step_untimed_pass", "parity_checked_captures") if k in r}
+            sub[name]["captures"] = ncap
+        except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
+            sub[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    return sub
+
+
+def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup, cpu=True, use_dist=False, world=1, rank=0):
+    """Scanner path (BASELINE configs 3/5): D captures resident in HBM -> snr, num_hit per capture on the host."""
     import torch.distributed as dist
 
-    import gsmcal
     from gsmcal import synth
-    D, frames = args.streams, args.frames
+    from oracle import gsmcal_oracle as oracle
     N = frames * synth.FRAME_OV
     coef = np.ascontiguousarray(synth.fir1(30, 200e3 / synth.FS))     # multi_rtl_sdr_gsm_FCCH_scanner.m:53
-    nd = max(1, min(args.distinct, D))
-    distinct = np.stack([synth.make_stream(dongle=1000 + rank, arfcn=i, num_frames=frames, bcch=(i % 4 != 3))[0]
-                         for i in range(nd)])
-    raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device
+    nd = max(1, min(distinct, D))
+    base = np.stack([synth.make_stream(dongle=1000 + rank, arfcn=i, num_frames=frames, bcch=(i % 4 != 3))[0] for i in range(nd)])
+    base_t = torch.from_numpy(base).to(dev)
+    raw_t = torch.empty((D, 2 * N), dtype=torch.uint8, device=dev)
+    # distinct captures generated on the device (rotation + counter-based dither of the seeded base set; synth.expand_capture
+    # is the bit-identical host twin used for the parity check below)
+    first_unit = rank * D
+    gsmcal.synth_expand_dev(base_t.data_ptr(), nd, N, raw_t.data_ptr(), D, first_unit=first_unit, ctx=ctx)
+    ctx.sync()
     out_t = torch.zeros((D, 2), dtype=torch.float64, device=dev)
+    host_out = torch.zeros((D, 2), dtype=torch.float64).pin_memory()
     gathered = torch.zeros((world * D, 2), dtype=torch.float64, device=dev) if use_dist else None
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = gsmcal.Context(int(os.environ.get("LOCAL_RANK", "0")), stream=stream.cuda_stream)
     cp = coef.ctypes.data_as(gsmcal._lib.c_double_p)
 
     def step():
@@ -332,6 +409,7 @@ def bench_scan(args, rank, world, dev, use_dist):
                                                      C.c_void_p(out_t.data_ptr()), None, None, None), "scan")
         if use_dist:
             dist.all_gather_into_tensor(gathered, out_t)
+        host_out.copy_(out_t, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -339,62 +417,70 @@ def bench_scan(args, rank, world, dev, use_dist):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = time_steps(torch, dev, step, steps, warmup, fence)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    prof = {}
-    if not args.no_kernel_events and rank == 0:     # untimed pass: per-kernel breakdown (HIP events on the launch stream)
-        ctx.profile_reset()
-        ctx.profile_filter(None)
-        ctx.profile_enable(True)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        prof = ctx.profile_get()
-        ctx.profile_enable(False)
-    res = out_t.cpu().numpy()
-    value = world * D * N * args.steps / elapsed / 1e6
-    out = {"metric": "IQ Msamples/s through FCCH scanner path", "value": round(value, 3), "unit": "Msample/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+    res = host_out.numpy().copy()
+    value = world * D * N * steps / elapsed / 1e6
+    out = {"ms_per_step": round(1e3 * elapsed / steps, 4), "value": round(value, 3),
+           "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1),
+           "path_frac_of_hbm": round(value * 1e6 * 2.25 / 1e9 / HBM_PEAK_GBS / world, 4),
+           "captures_with_hits": int(np.sum(res[:, 1] > 0))}
+    if not args.no_kernel_events and rank == 0:
+        prof = event_pass(ctx, step, steps, torch, dev)
+        out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        for k, v in prof.items():
+            if k.startswith("k_front"):
+                ms = v[0] / v[1]
+                per_launch = D * N * 2.25 * steps / v[1]
+                out["front_kernel"] = {"name": k, "achieved_GBps": round(per_launch / 1e9 / (ms * 1e-3), 1), "avg_launch_ms": round(ms, 5)}
+    # parity: sampled captures through the CPU oracle (the host twin rebuilds their bytes)
+    rng = np.random.default_rng(11)
+    units = sorted(set([0, D - 1] + [int(x) for x in rng.integers(0, D, 14)]))
+    t_cpu = 0.0
+    for u in units:
+        cap = synth.expand_capture(base, first_unit + u)
+        c0 = time.perf_counter()
+        o = oracle.scan_capture(cap, coef)
+        t_cpu += time.perf_counter() - c0
+        assert o["num_hit"] == res[u, 1] and abs(o["snr"] - res[u, 0]) < 1e-8, f"scan parity, capture {u}"
+    out["parity_checked_captures"] = len(units)
+    if cpu:
+        out["cpu_baseline"] = {"value": round(len(units) * N / t_cpu / 1e6, 4), "unit": "Msample/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(units)} captures through oracle.scan_capture in {t_cpu:.1f} s"}
+    del raw_t
+    return out
+
+
+def bench_scan_main(args, rank, world, dev, use_dist):
+    import torch
+    import torch.distributed as dist
+
+    import gsmcal
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = gsmcal.Context(int(os.environ.get("LOCAL_RANK", "0")), stream=stream.cuda_stream)
+    r = bench_scan(args, torch, gsmcal, dev, ctx, args.streams, args.frames, args.distinct, args.steps, args.warmup,
+                   cpu=not args.no_cpu_baseline and world == 1, use_dist=use_dist, world=world, rank=rank)
+    D, N = args.streams, args.frames * 10000
+    out = {"metric": "IQ Msamples/s through FCCH scanner path", "value": r["value"], "unit": "Msample/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-           "data": f"synthetic GSM uint8 IQ, {nd} distinct captures tiled to {D} (3 of 4 carry a BCCH carrier)",
+           "data": f"synthetic GSM uint8 IQ: {min(args.distinct, D)} seeded captures expanded on the device to {D} distinct ones "
+                   "(3 of 4 base captures carry a BCCH carrier)",
            "config": {"workload": f"scanner path multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,164-185: {D} captures/GPU x {N} "
-                                  f"IQ samples ({frames} frames), fir1(30)", "captures_per_gpu": D,
-                      "captures_with_hits": int(np.sum(res[:, 1] > 0)), "bytes_per_sample_algorithmic": 2.25},
-           "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1)}
+                                  f"IQ samples ({args.frames} frames), fir1(30), snr/num_hit on the host", "captures_per_gpu": D,
+                      "captures_with_hits": r["captures_with_hits"], "bytes_per_sample_algorithmic": 2.25},
+           "roofline": {"bound": "hbm", "achieved": r["hbm_GBps_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": r["path_frac_of_hbm"], "traffic": None,
+                        "what": "WHOLE PATH: Msample/s x 2.25 B/sample (2 B raw read + 16/64 B decimated write)",
+                        "kernel": r.get("front_kernel")}}
+    for k in ("kernels_ms_per_step_untimed_pass", "parity_checked_captures", "cpu_baseline"):
+        if k in r:
+            out[k] = r[k]
     if rank == 0:
-        if prof:
-            out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / args.steps, 4)
-                                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-            for k, v in prof.items():
-                if k.startswith("k_front") and v[1]:
-                    ms = v[0] / v[1]
-                    per_launch = D * N * 2.25 * args.steps / v[1]     # the batch may be split over internal lanes
-                    ach = per_launch / 1e9 / (ms * 1e-3)
-                    out["roofline"] = {"kernel": k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                       "avg_launch_ms": round(ms, 5),
-                                       "note": "2 B/sample raw read + 16/64 B/sample decimated complex-double write"}
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import gsmcal_oracle as oracle
-            t_cpu, done = 0.0, 0
-            while t_cpu < args.cpu_seconds and done < nd:
-                c0 = time.perf_counter()
-                o = oracle.scan_capture(distinct[done], coef)
-                t_cpu += time.perf_counter() - c0
-                assert o["num_hit"] == res[done, 1] and abs(o["snr"] - res[done, 0]) < 1e-8, "scan parity"
-                done += 1
-            out["cpu_baseline"] = {"value": round(done * N / t_cpu / 1e6, 4), "unit": "Msample/s", "cores": 1, "kind": "port",
-                                   "sample": f"{done} captures through oracle.scan_capture in {t_cpu:.1f} s"}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -412,11 +498,12 @@ def _oracle_one(args):
     return oracle.calibrate_stream(raw, coef, ts, fc)["total_sampling_ppm"]
 
 
-def _pos_info(pos_t, table, i):
+def _pos_info(pos, table, i):
+    """pos: (D, 2, MAX_POS_ROWS) host array"""
     k = int(table[i, 7])
     if table[i, 8] == -1.0:
         return -np.ones((k, 2))
-    return pos_t[i, :, :k].cpu().numpy().T.copy()
+    return np.ascontiguousarray(pos[i, :, :k].T)
 
 
 if __name__ == "__main__":
