@@ -47,6 +47,7 @@ struct Lane {
     DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
+    hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
 };
 
@@ -598,11 +599,14 @@ int upload_array(gsmcal_ctx* c, const double* s, size_t n_cplx) {
 
 // Split d units over the lanes: returns the number of lanes used and fills lo/n per lane.
 int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
-    // lanes pay off where the chain is a string of short latency-bound kernels (calibration); the scanner path is
-    // two bandwidth-bound kernels that only get in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms
-    // for 12,800 captures)
-    int nl = latency_bound ? c->n_lanes_cfg : 1;
-    if (nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
+    // Calibration chain (a string of short latency-bound kernels): lanes run side by side.  Scanner path: one
+    // bandwidth-bound front kernel followed by the compute-bound detector -- side-by-side lanes only put two front
+    // kernels in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms for 12,800 captures), so big scanner
+    // batches are cut into pipeline stages instead: the front kernels run one after the other (chained by events) and
+    // each stage's detector runs underneath the next stage's front kernel.
+    int nl = latency_bound ? c->n_lanes_cfg : (d >= 2048 ? 8 : 1);
+    if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
+    if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;
     for (int i = 0; i < nl; ++i) {
         c->lanes[i].lo = (int)(((long)i * d) / nl);
@@ -791,6 +795,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
+        if (L.front_done) (void)hipEventDestroy(L.front_done);
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -1230,7 +1235,12 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const int lo = L.lo, S = L.n;
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
+        if (nl > 1) {                                       // pipeline: this front kernel starts when the previous stage's has finished
+            if (!L.front_done) HIPCHK(c, hipEventCreateWithFlags(&L.front_done, hipEventDisableTiming));
+            if (i > 0) HIPCHK(c, hipStreamWaitEvent(L.stream, c->lanes[i - 1].front_done, 0));
+        }
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
+        if (nl > 1) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
         RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
