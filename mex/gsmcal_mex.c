@@ -7,9 +7,15 @@
  *
  *   for f in raw2iq chn_filter_8x_4x chn_filter_4x move_fft_snr_runtime_avg specific_fft_snr_fix_avg \
  *            FCCH_coarse_position FCCH_fine_correction SCH_corr_rate_correction \
- *            carrier_correct_post_SCH total_ppm_calculation; do
+ *            carrier_correct_post_SCH total_ppm_calculation gsmcal_calibrate gsmcal_fcch_scan; do
  *     mex -R2018a -DGSMCAL_FN_$f -output $f mex/gsmcal_mex.c -Iinclude -Lmulti-rtl-sdr-calibration_amd/lib -lgsmcal
  *   done
+ *
+ * The last two are not shadows of .m files: they are the fused entry points (one call per driver loop body)
+ *   [table, pos_info] = gsmcal_calibrate(s, coef, sch_training_sequence, freq)   replaces gsm_sync_demod.m:107-124
+ *   [snr, num_hit]    = gsmcal_fcch_scan(s, coef)                                replaces ..FCCH_scanner.m:132-135,163-186
+ * with s the 2N x D uint8 matrix fread() delivers (gsm_sync_demod.m:96; pass uint8(s) if it was read as double).
+ * tests/test_abi_cpu.py compiles every target against a declaration-only mex.h (tests/mex_stub) as a prototype check.
  *
  * -R2018a selects the interleaved-complex API, which matches the ABI's interleaved double[2].
  * Argument lists, 1-based positions, row/column shapes and sentinels follow the .m files
@@ -172,8 +178,52 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double out;
     gsmcal_total_ppm_calculation(mxGetDoubles(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out);
     plhs[0] = scalar(out);
+#elif defined(GSMCAL_FN_gsmcal_calibrate)
+    /* [table, pos_info] = gsmcal_calibrate(s, coef, sch_training_sequence, freq)      gsm_sync_demod.m:107-124 for all dongles
+     * s: 2N x D uint8 (column = one dongle's interleaved I,Q bytes, exactly the ABI's capture-major layout);
+     * table: D x 10 (columns: GSMCAL_T_*); pos_info: 1 x D cell, pos_info{i} = R x 2 (or the all -1 sentinel) */
+    mwSize rows2n = mxGetM(prhs[0]), d = mxGetN(prhs[0]), nts, i, k;
+    const double* ts = cplx_in(prhs[2], &nts);
+    const mwSize ncf = mxGetNumberOfElements(prhs[3]);
+    double* cf = (double*)mxMalloc(d * sizeof(double));
+    double* tab = (double*)mxMalloc(d * GSMCAL_TABLE_COLS * sizeof(double));
+    double* pi = (double*)mxMalloc(d * 2 * GSMCAL_MAX_POS_ROWS * sizeof(double));
+    if (!mxIsUint8(prhs[0])) mexErrMsgIdAndTxt("gsmcal:type", "s must be uint8 (the bytes fread(...,'uint8') delivers)");
+    for (i = 0; i < d; ++i) cf[i] = mxGetDoubles(prhs[3])[ncf == d ? i : 0];
+    chk(gsmcal_calibrate_batch(ctx(), (const uint8_t*)mxGetUint8s(prhs[0]), (int)d, (long)(rows2n / 2), mxGetDoubles(prhs[1]),
+                               (int)mxGetNumberOfElements(prhs[1]), ts, (int)nts, cf, tab, pi, NULL, NULL), "gsmcal_calibrate");
+    plhs[0] = mxCreateDoubleMatrix(d, GSMCAL_TABLE_COLS, mxREAL);
+    for (i = 0; i < d; ++i)
+        for (k = 0; k < GSMCAL_TABLE_COLS; ++k) mxGetDoubles(plhs[0])[k * d + i] = tab[i * GSMCAL_TABLE_COLS + k];
+    if (nlhs > 1) {
+        plhs[1] = mxCreateCellMatrix(1, d);
+        for (i = 0; i < d; ++i) {
+            const mwSize r = (mwSize)tab[i * GSMCAL_TABLE_COLS + GSMCAL_T_N_POS_ROWS];
+            mxArray* m = mxCreateDoubleMatrix(r, 2, mxREAL);
+            for (k = 0; k < r; ++k) {
+                mxGetDoubles(m)[k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + k];
+                mxGetDoubles(m)[r + k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + GSMCAL_MAX_POS_ROWS + k];
+            }
+            mxSetCell(plhs[1], i, m);
+        }
+    }
+    mxFree(cf); mxFree(tab); mxFree(pi);
+
+#elif defined(GSMCAL_FN_gsmcal_fcch_scan)
+    /* [snr, num_hit] = gsmcal_fcch_scan(s, coef)      multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,163-186 for all captures
+     * s: 2N x F uint8, one column per (dongle, frequency) capture in the order of s_all (:135); snr, num_hit: 1 x F */
+    mwSize rows2n = mxGetM(prhs[0]), f = mxGetN(prhs[0]);
+    if (!mxIsUint8(prhs[0])) mexErrMsgIdAndTxt("gsmcal:type", "s must be uint8 (the bytes fread(...,'uint8') delivers)");
+    plhs[0] = mxCreateDoubleMatrix(1, f, mxREAL);
+    {
+        mxArray* nh = mxCreateDoubleMatrix(1, f, mxREAL);
+        chk(gsmcal_fcch_scan_batch(ctx(), (const uint8_t*)mxGetUint8s(prhs[0]), (int)f, (long)(rows2n / 2), mxGetDoubles(prhs[1]),
+                                   (int)mxGetNumberOfElements(prhs[1]), mxGetDoubles(plhs[0]), mxGetDoubles(nh), NULL, NULL, NULL),
+            "gsmcal_fcch_scan");
+        if (nlhs > 1) plhs[1] = nh;
+    }
 #else
 #error "define one GSMCAL_FN_<function> (see the header comment)"
 #endif
-    (void)nrhs;
+    (void)nrhs; (void)nlhs;
 }
