@@ -202,6 +202,24 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, lon
                                const double* carrier_freq, double* d_table, double* d_pos_info,
                                double* d_r_correct, long* d_r_len);
 
+/* ---- multi-GPU: one process per GPU, ONE collective ---------------------------------------------------------------
+ * The reference has no distributed layer; units (dongle streams, ARFCN captures) are independent (gsm_sync_demod.m:112,
+ * multi_rtl_sdr_gsm_FCCH_scanner.m:60-65,163), so ranks shard them block-contiguously and exchange only the result
+ * table every rank needs for the inter-dongle comparison (gsm_sync_demod.m:151-158).  RCCL (librccl.so, loaded on first
+ * use) over xGMI; the all-gather is enqueued on the context's stream right behind the kernels that fill the table.
+ * Bootstrap: rank 0 obtains a 128-byte id and hands it to the other ranks by any means (gsmcal_comm_init_rank), or all
+ * ranks name the same file on a shared filesystem (gsmcal_comm_init_file: rank 0 writes the id, the others wait for it). */
+typedef struct gsmcal_comm gsmcal_comm;
+#define GSMCAL_COMM_ID_BYTES 128
+int gsmcal_comm_get_unique_id(void* id_out /* GSMCAL_COMM_ID_BYTES */);
+int gsmcal_comm_init_rank(gsmcal_ctx* ctx, const void* id, int world, int rank, gsmcal_comm** out);
+int gsmcal_comm_init_file(gsmcal_ctx* ctx, const char* path, int world, int rank, gsmcal_comm** out);
+void gsmcal_comm_destroy(gsmcal_comm* comm);
+/* d_all[r][i][c] = rank r's d_local[i][c]: rows_per_rank x cols doubles per rank (ranks with fewer units pad their block,
+ * e.g. with NaN); device pointers; enqueued on the context's stream (gsmcal_sync() before reading d_all on the host). */
+int gsmcal_allgather_table(gsmcal_ctx* ctx, gsmcal_comm* comm, const double* d_local, int rows_per_rank, int cols,
+                           double* d_all);
+
 /* Synthetic-input utility for benchmarks and tests (NOT part of the reference's path; SURVEY 8d: the 131 GB scanner
  * configuration is generated on the device).  Expands k seeded base captures (d_base: [k][2n] bytes) into d distinct
  * captures d_out: [d][2n]: capture first_unit+j = base[(first_unit+j) mod k] rotated by a per-capture number of

@@ -66,6 +66,11 @@ SIGNATURES = {
     "gsmcal_calibrate_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, c_double_p, C.c_int,
                                              c_double_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
+    "gsmcal_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "gsmcal_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_comm_init_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_comm_destroy": (None, [C.c_void_p]),
+    "gsmcal_allgather_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gsmcal_synth_expand_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                           C.c_ulonglong]),
     "gsmcal_last_batch_details": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libgsmcal.so cannot be built (there is no CPU fallback)")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB + ".tmp", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=HERE)

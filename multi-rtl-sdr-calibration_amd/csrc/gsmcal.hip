@@ -14,6 +14,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
 #include "../../include/gsmcal.h"
 #include "builtin_taps.h"
 #include "kernels_detect.h"
@@ -1365,6 +1369,110 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     if (r_correct)
         HIPCHK(c, hipMemcpyAsync(r_correct, c->arr_out.p, (size_t)d * n * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- multi-GPU: RCCL all-gather of the result table ------------------------------------------------------------
+// librccl.so is loaded on first use, so single-GPU users of libgsmcal.so do not depend on it.
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    if (api.h) return &api;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return nullptr;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) return nullptr;
+    api.h = h;
+    return &api;
+}
+struct gsmcal_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+};
+static_assert(GSMCAL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+
+int gsmcal_comm_get_unique_id(void* id_out) {
+    if (!id_out) return GSMCAL_E_ARG;
+    RcclApi* a = rccl_api();
+    if (!a) return GSMCAL_E_UNSUPPORTED;
+    ncclUniqueId id;
+    if (a->GetUniqueId(&id) != ncclSuccess) return GSMCAL_E_HIP;
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int gsmcal_comm_init_rank(gsmcal_ctx* c, const void* idp, int world, int rank, gsmcal_comm** out) {
+    if (!c || !idp || !out || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
+    *out = nullptr;
+    RcclApi* a = rccl_api();
+    if (!a) { c->err = "librccl.so could not be loaded"; return GSMCAL_E_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, idp, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = a->CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) {
+        c->err = std::string("ncclCommInitRank: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
+        return GSMCAL_E_HIP;
+    }
+    gsmcal_comm* g = new gsmcal_comm();
+    g->comm = comm; g->world = world; g->rank = rank;
+    *out = g;
+    return 0;
+}
+
+int gsmcal_comm_init_file(gsmcal_ctx* c, const char* path, int world, int rank, gsmcal_comm** out) {
+    if (!c || !path || !out || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
+    unsigned char id[GSMCAL_COMM_ID_BYTES];
+    if (rank == 0) {
+        RET_IF(gsmcal_comm_get_unique_id(id));
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); c->err = "cannot write the id file"; return GSMCAL_E_ARG; }
+        fclose(f);
+        if (rename(tmp.c_str(), path) != 0) { c->err = "cannot publish the id file"; return GSMCAL_E_ARG; }   // atomic: readers never see half an id
+    } else {
+        bool ok = false;
+        for (int tries = 0; tries < 6000 && !ok; ++tries) {             // up to ~60 s
+            FILE* f = fopen(path, "rb");
+            if (f) { ok = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+            if (!ok) usleep(10000);
+        }
+        if (!ok) { c->err = "timed out waiting for rank 0's id file"; return GSMCAL_E_ARG; }
+    }
+    return gsmcal_comm_init_rank(c, id, world, rank, out);
+}
+
+void gsmcal_comm_destroy(gsmcal_comm* g) {
+    if (!g) return;
+    RcclApi* a = rccl_api();
+    if (a && g->comm) (void)a->CommDestroy(g->comm);
+    delete g;
+}
+
+int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local, int rows_per_rank, int cols, double* d_all) {
+    if (!c || !g || !d_local || !d_all || rows_per_rank < 1 || cols < 1) return GSMCAL_E_ARG;
+    RcclApi* a = rccl_api();
+    if (!a) return GSMCAL_E_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, c->stream);
+    if (r != ncclSuccess) {
+        c->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
+        return GSMCAL_E_HIP;
+    }
     return 0;
 }
 

@@ -44,6 +44,41 @@ def allgather_table(local_table, num_units: int, group=None):
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+class NativeComm:
+    """The same collective without PyTorch: gsmcal_allgather_table of the C ABI (RCCL, enqueued on the context's
+    stream).  Bootstrap by a file every rank can see (rank 0 writes the 128-byte id) or by an id passed in."""
+
+    def __init__(self, ctx, world, rank, id_file=None, unique_id=None):
+        import ctypes as C
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        h = C.c_void_p()
+        if unique_id is not None:
+            buf = C.create_string_buffer(bytes(unique_id), 128)
+            rc = ctx.lib.gsmcal_comm_init_rank(ctx.h, buf, self.world, self.rank, C.byref(h))
+        else:
+            rc = ctx.lib.gsmcal_comm_init_file(ctx.h, str(id_file).encode(), self.world, self.rank, C.byref(h))
+        ctx.check(rc, "gsmcal_comm_init")
+        self.h = h
+
+    @staticmethod
+    def unique_id(ctx):
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        ctx.check(ctx.lib.gsmcal_comm_get_unique_id(buf), "gsmcal_comm_get_unique_id")
+        return buf.raw
+
+    def allgather_table(self, d_local, rows_per_rank, cols, d_all):
+        """device pointers (ints); enqueues only"""
+        import ctypes as C
+        self.ctx.check(self.ctx.lib.gsmcal_allgather_table(self.ctx.h, self.h, C.c_void_p(d_local), int(rows_per_rank),
+                                                           int(cols), C.c_void_p(d_all)), "gsmcal_allgather_table")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gsmcal_comm_destroy(self.h)
+            self.h = None
+
+
 def sampling_phase_difference(pos_info_a, pos_info_b):
     """gsm_sync_demod.m:151-158: per-burst start difference between two dongles' pos_info (8x units)."""
     a = np.atleast_2d(np.asarray(pos_info_a, dtype=np.float64))

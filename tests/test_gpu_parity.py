@@ -512,3 +512,27 @@ def test_randomised_sweep_against_oracle(g, setup):
         parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
         calibrated += out["table"][i, 9] == 0
     assert calibrated >= n // 2
+
+
+def test_native_allgather_of_the_table_single_rank(g, ctx, setup, tmp_path):
+    """gsmcal_allgather_table (RCCL through the C ABI, no PyTorch): with one rank the gathered table is the local one;
+    both bootstraps (id handed over, id through a file) are exercised.  The multi-rank layout is covered on CPU by
+    tests/test_dist_cpu.py (gloo) -- the driver takes the real 8-GPU curve."""
+    from gsmcal import dist as gd
+    rows, cols = 5, g.TABLE_COLS
+    local = np.arange(rows * cols, dtype=np.float64).reshape(rows, cols) + 0.25
+    d_loc, d_all = ctx.alloc(local.nbytes), ctx.alloc(local.nbytes)
+    try:
+        ctx.h2d(d_loc, local)
+        for kw in ({"unique_id": gd.NativeComm.unique_id(ctx)}, {"id_file": tmp_path / "gsmcal_id"}):
+            comm = gd.NativeComm(ctx, 1, 0, **kw)
+            try:
+                comm.allgather_table(d_loc, rows, cols, d_all)
+                ctx.sync()
+                got = np.zeros_like(local)
+                ctx.d2h(got, d_all)
+                assert np.array_equal(got, local)
+            finally:
+                comm.close()
+    finally:
+        ctx.free(d_loc); ctx.free(d_all)

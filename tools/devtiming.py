@@ -29,7 +29,7 @@ def main():
     src = os.path.join(PKG, "csrc", "gsmcal.hip")
     if not os.path.exists(DEV) or os.path.getmtime(DEV) < max(os.path.getmtime(os.path.join(PKG, "csrc", f)) for f in os.listdir(os.path.join(PKG, "csrc"))):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                        "-DGSMCAL_DEVTIMING", src, "-o", DEV], check=True)
+                        "-DGSMCAL_DEVTIMING", src, "-o", DEV, "-ldl"], check=True)
     os.environ["GSMCAL_LIB"] = DEV
     os.environ["GSMCAL_GRAPH"] = "0"
     import numpy as np
