@@ -379,7 +379,50 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream):
         except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
             sub[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
+    try:
+        sub["ingest_ring"] = bench_ingest(torch, gsmcal, dev, ctx)
+    except Exception as e:  # noqa: BLE001
+        sub["ingest_ring"] = {"error": repr(e)}
     return sub
+
+
+def bench_ingest(torch, gsmcal, dev, ctx, D=256, nbatch=8):
+    """scanner batches through the pinned ring (H2D of batch k+1 under the detector of batch k) -- sustained
+    input rate next to the plain pinned hipMemcpy rate of the same bytes (the PCIe ceiling of this box)."""
+    from gsmcal import synth
+    N = 64 * synth.FRAME_OV
+    coef = np.ascontiguousarray(synth.fir1(30, 200e3 / synth.FS))
+    nbytes = D * 2 * N
+    ring = gsmcal.ingest.Ring(ctx, nbytes, slots=2)
+    out_t = torch.zeros((nbatch, D, 2), dtype=torch.float64, device=dev)
+    base = np.stack([synth.make_stream(dongle=1200, arfcn=i, num_frames=64, bcch=(i % 4 != 3))[0] for i in range(8)])
+    for s in range(2):
+        ring.host(s).reshape(D, 2 * N)[:] = np.tile(base, (D // 8, 1))      # the producer's bytes are already in the pinned slots
+    try:
+        def run(with_compute):
+            ctx.sync()
+            t0 = time.perf_counter()
+            for k in range(nbatch):
+                s = k % 2
+                if k >= 2:
+                    ring.host_ready(s)
+                ring.submit(s)
+                dev_p = ring.acquire(s)
+                if with_compute:
+                    gsmcal.fcch_scan_batch_dev(dev_p, D, N, coef, out_t[k].data_ptr(), ctx=ctx)
+                ring.release(s)
+            ctx.sync()
+            return time.perf_counter() - t0
+        run(True)
+        t_pipe = min(run(True) for _ in range(3))
+        t_copy = min(run(False) for _ in range(3))
+    finally:
+        ring.close()
+    tot = nbatch * nbytes
+    return {"batches": nbatch, "captures_per_batch": D, "bytes_per_batch": nbytes,
+            "sustained_GBps_with_detector": round(tot / t_pipe / 1e9, 2), "h2d_only_GBps": round(tot / t_copy / 1e9, 2),
+            "Msample_per_s": round(nbatch * D * N / t_pipe / 1e6, 1),
+            "note": "host-resident input: the path is PCIe-bound; this figure is never `value` (inputs resident in HBM)"}
 
 
 def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup, cpu=True, use_dist=False, world=1, rank=0):

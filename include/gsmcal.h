@@ -220,6 +220,29 @@ void gsmcal_comm_destroy(gsmcal_comm* comm);
 int gsmcal_allgather_table(gsmcal_ctx* ctx, gsmcal_comm* comm, const double* d_local, int rows_per_rank, int cols,
                            double* d_all);
 
+/* ---- ingest ring: rtl_tcp bytes -> pinned host ring -> asynchronous H2D ----------------------------------
+ * The reference reads every capture with fread(tcp_obj, 2*num_sample, 'uint8') into MATLAB memory and processes it in
+ * place (gsm_sync_demod.m:94-104, multi_rtl_sdr_gsm_FCCH_scanner.m:117-131).  Here the socket reader writes straight into
+ * a pinned host slot, the slot goes to its device twin on a copy stream, and the copy of batch k+1 runs under the kernels
+ * of batch k.  A ring has `slots` (>= 2) slots of `batch_bytes`; per slot the cycle is
+ *     host = gsmcal_ring_host(ring, s)          the producer fills it (recv() target, zero copy)
+ *     gsmcal_ring_submit(ring, s)               async H2D on the ring's copy stream (waits, on the GPU, for the
+ *                                               consumer's previous use of the slot)
+ *     dev = gsmcal_ring_acquire(ring, s)        the context's stream waits (on the GPU) for that copy; returns the
+ *                                               device buffer to hand to a *_dev entry point
+ *     gsmcal_ring_release(ring, s)              after enqueueing the consumer: the slot may be overwritten once it is done
+ *     gsmcal_ring_host_ready(ring, s)           host-side wait until the slot's H2D has finished, i.e. until the pinned
+ *                                               host buffer may be refilled
+ * No call blocks the host except gsmcal_ring_host_ready. */
+typedef struct gsmcal_ring gsmcal_ring;
+int gsmcal_ring_create(gsmcal_ctx* ctx, size_t batch_bytes, int slots, gsmcal_ring** out);
+void gsmcal_ring_destroy(gsmcal_ring* ring);
+void* gsmcal_ring_host(gsmcal_ring* ring, int slot);
+int gsmcal_ring_submit(gsmcal_ring* ring, int slot, size_t bytes);
+void* gsmcal_ring_acquire(gsmcal_ring* ring, int slot);
+int gsmcal_ring_release(gsmcal_ring* ring, int slot);
+int gsmcal_ring_host_ready(gsmcal_ring* ring, int slot);
+
 /* Synthetic-input utility for benchmarks and tests (NOT part of the reference's path; SURVEY 8d: the 131 GB scanner
  * configuration is generated on the device).  Expands k seeded base captures (d_base: [k][2n] bytes) into d distinct
  * captures d_out: [d][2n]: capture first_unit+j = base[(first_unit+j) mod k] rotated by a per-capture number of

@@ -5,9 +5,10 @@ valid Python identifier).  Sub-modules:
     api    -- host mirror of the reference's MATLAB functions + batched entry points (ctypes -> HIP)
     synth  -- seeded synthetic GSM IQ, GMSK modulator, fir1
     dist   -- multi-GPU sharding + all-gather of the calibration table (torch.distributed, RCCL)
+    ingest -- rtl_tcp framing (command packets, flush, capture reads) + the pinned ring / async H2D of the C ABI
     build  -- hipcc build of csrc/ -> lib/libgsmcal.so
 """
-from . import build, synth  # noqa: F401
+from . import build, ingest, synth  # noqa: F401
 from ._lib import GsmcalError, MAX_HITS, MAX_POS_ROWS, TABLE_COLS, SIGNATURES, lib_path, load  # noqa: F401
 from .api import (  # noqa: F401
     Context, default_context, raw2iq, filter, chn_filter_8x_4x, chn_filter_4x, move_fft_snr_runtime_avg,

@@ -71,6 +71,13 @@ SIGNATURES = {
     "gsmcal_comm_init_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmcal_comm_destroy": (None, [C.c_void_p]),
     "gsmcal_allgather_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gsmcal_ring_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_ring_destroy": (None, [C.c_void_p]),
+    "gsmcal_ring_host": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gsmcal_ring_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "gsmcal_ring_acquire": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gsmcal_ring_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "gsmcal_ring_host_ready": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmcal_synth_expand_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                           C.c_ulonglong]),
     "gsmcal_last_batch_details": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -1476,6 +1476,83 @@ int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local,
     return 0;
 }
 
+// ---- ingest ring ---------------------------------------------------------------------------------------------------
+struct gsmcal_ring {
+    gsmcal_ctx* c = nullptr;
+    size_t bytes = 0;
+    int n = 0;
+    hipStream_t copy = nullptr;
+    std::vector<void*> host, dev;
+    std::vector<hipEvent_t> copied, consumed;      // H2D of the slot done / consumer kernels of the slot done
+    std::vector<char> has_consumed;
+};
+
+int gsmcal_ring_create(gsmcal_ctx* c, size_t batch_bytes, int slots, gsmcal_ring** out) {
+    if (!c || !out || batch_bytes < 1 || slots < 2 || slots > 16) return GSMCAL_E_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    gsmcal_ring* r = new gsmcal_ring();
+    r->c = c; r->bytes = batch_bytes; r->n = slots;
+    r->host.assign(slots, nullptr); r->dev.assign(slots, nullptr);
+    r->copied.assign(slots, nullptr); r->consumed.assign(slots, nullptr); r->has_consumed.assign(slots, 0);
+    bool ok = hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < slots; ++i) {
+        ok = hipHostMalloc(&r->host[i], batch_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc(&r->dev[i], batch_bytes) == hipSuccess &&
+             hipEventCreateWithFlags(&r->copied[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&r->consumed[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { c->err = "ring allocation failed"; gsmcal_ring_destroy(r); return GSMCAL_E_HIP; }
+    *out = r;
+    return 0;
+}
+
+void gsmcal_ring_destroy(gsmcal_ring* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->c->device);
+    if (r->copy) (void)hipStreamSynchronize(r->copy);
+    (void)hipStreamSynchronize(r->c->stream);
+    for (int i = 0; i < r->n; ++i) {
+        if (r->host[i]) (void)hipHostFree(r->host[i]);
+        if (r->dev[i]) (void)hipFree(r->dev[i]);
+        if (r->copied[i]) (void)hipEventDestroy(r->copied[i]);
+        if (r->consumed[i]) (void)hipEventDestroy(r->consumed[i]);
+    }
+    if (r->copy) (void)hipStreamDestroy(r->copy);
+    delete r;
+}
+
+void* gsmcal_ring_host(gsmcal_ring* r, int slot) { return (r && slot >= 0 && slot < r->n) ? r->host[slot] : nullptr; }
+
+int gsmcal_ring_submit(gsmcal_ring* r, int slot, size_t bytes) {
+    if (!r || slot < 0 || slot >= r->n || bytes > r->bytes) return GSMCAL_E_ARG;
+    gsmcal_ctx* c = r->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (r->has_consumed[slot]) HIPCHK(c, hipStreamWaitEvent(r->copy, r->consumed[slot], 0));   // the device twin is free again
+    HIPCHK(c, hipMemcpyAsync(r->dev[slot], r->host[slot], bytes ? bytes : r->bytes, hipMemcpyHostToDevice, r->copy));
+    HIPCHK(c, hipEventRecord(r->copied[slot], r->copy));
+    return 0;
+}
+
+void* gsmcal_ring_acquire(gsmcal_ring* r, int slot) {
+    if (!r || slot < 0 || slot >= r->n) return nullptr;
+    if (hipStreamWaitEvent(r->c->stream, r->copied[slot], 0) != hipSuccess) return nullptr;
+    return r->dev[slot];
+}
+
+int gsmcal_ring_release(gsmcal_ring* r, int slot) {
+    if (!r || slot < 0 || slot >= r->n) return GSMCAL_E_ARG;
+    HIPCHK(r->c, hipEventRecord(r->consumed[slot], r->c->stream));
+    r->has_consumed[slot] = 1;
+    return 0;
+}
+
+int gsmcal_ring_host_ready(gsmcal_ring* r, int slot) {
+    if (!r || slot < 0 || slot >= r->n) return GSMCAL_E_ARG;
+    HIPCHK(r->c, hipEventSynchronize(r->copied[slot]));
+    return 0;
+}
+
 // ---- synthetic-input utility ---------------------------------------------------------------------------
 int gsmcal_synth_expand_dev(gsmcal_ctx* c, const uint8_t* d_base, int k, long n, uint8_t* d_out, long d, long first_unit,
                             unsigned long long seed) {

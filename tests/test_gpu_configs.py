@@ -136,3 +136,36 @@ def test_config3_two_dongle_100_arfcn_sweep(g_mod, ctx):
     for k in ("snr", "num_hit", "freq", "coef"):
         assert np.allclose(rec[k], ref[k], rtol=0, atol=parity.SNR_ATOL)
     assert rec["filename"] == ref["filename"] and rec["observe_time"] == N / g.synth.FS and rec["freq"].shape == (2, 100)
+
+
+def test_ingest_ring_overlaps_copies_with_the_detector(g_mod, ctx):
+    """batches written into the pinned ring (what recv_into() does), copied on the ring's stream while the
+    previous batch is processed, consumed through the *_dev entry point -- results identical to the host-pointer call."""
+    g = g_mod
+    ing = g.ingest
+    D, nbatch = 24, 5
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)
+    base = _base_captures(g, 12, 7000)
+    batches = [np.stack([g.synth.expand_capture(base, 1000 * k + i) for i in range(D)]) for k in range(nbatch)]
+    ring = ing.Ring(ctx, D * 2 * N, slots=2)
+    d_out = ctx.alloc(nbatch * D * 16)
+    try:
+        for k in range(nbatch):
+            s = k % 2
+            if k >= 2:
+                ring.host_ready(s)                                   # the slot's previous H2D has left the pinned buffer
+            ring.host(s)[:] = batches[k].reshape(-1)                 # stand-in for the socket reader's recv_into()
+            ring.submit(s)
+            dev = ring.acquire(s)
+            g.fcch_scan_batch_dev(dev, D, N, coef, d_out + k * D * 16, ctx=ctx)
+            ring.release(s)
+        ctx.sync()
+        got = np.empty((nbatch, D, 2))
+        ctx.d2h(got, d_out)
+    finally:
+        ring.close()
+        ctx.free(d_out)
+    for k in range(nbatch):
+        ref = g.fcch_scan_batch(batches[k], coef, ctx=ctx)
+        assert np.array_equal(got[k, :, 0], ref["snr"]) and np.array_equal(got[k, :, 1], ref["num_hit"]), f"batch {k}"
+    assert np.sum(got[:, :, 1] > 0) > 0
