@@ -164,6 +164,17 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* ctx, const double* s, long len, 
                                     int rows, int ld, int oversampling_ratio, double carrier_freq,
                                     double* r, long cap_r, long* len_r, double* carrier_ppm);
 
+/* Front end of SCH_demod(s,pos_info,training_sequence,ov)                SCH_demod.m:53-59,79-90
+ * Per SCH row of pos_info (type 1): the burst with 8 symbols either side and the traceback depth behind it
+ * (len_fde_ov = 194*ov samples), its frequency-domain channel estimate against the training sequence and the equalised
+ * burst x_eq = ifft(fft(x) ./ (fft(x_training) ./ fft(training))).  The Viterbi GMSK demodulator that follows in the
+ * reference (Communications Toolbox, output discarded) is not part of this library.
+ * x_eq: cap_bursts x len_fde_ov complex, burst-major; *num_bursts SCH bursts written, *len_fde_ov their length.
+ * pos_info all -1 (:8-11): returns GSMCAL_S_POST_NO_POS with *num_bursts = 0. */
+int gsmcal_SCH_equalise(gsmcal_ctx* ctx, const double* s, long len, const double* pos_info, int rows, int ld,
+                        const double* sch_training_sequence, int len_ts, int oversampling_ratio,
+                        double* x_eq, int cap_bursts, int* num_bursts, int* len_fde_ov);
+
 /* ppm_out = total_ppm_calculation(ppm_in)                           total_ppm_calculation.m:5-21
  * (pure host arithmetic; no context needed) */
 int gsmcal_total_ppm_calculation(const double* ppm_in, int n, double* ppm_out);

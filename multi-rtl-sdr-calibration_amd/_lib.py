@@ -52,6 +52,8 @@ SIGNATURES = {
                                                   C.c_long, c_long_p, c_double_p]),
     "gsmcal_carrier_correct_post_SCH": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, C.c_int,
                                                   C.c_int, C.c_double, c_double_p, C.c_long, c_long_p, c_double_p]),
+    "gsmcal_SCH_equalise": (C.c_int, [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_int, C.c_int, c_double_p, C.c_int,
+                                      C.c_int, c_double_p, C.c_int, c_int_p, c_int_p]),
     "gsmcal_total_ppm_calculation": (C.c_int, [c_double_p, C.c_int, c_double_p]),
     "gsmcal_frontend_batch": (C.c_int, [C.c_void_p, c_u8_p, C.c_int, C.c_long, c_double_p, C.c_int, C.c_int,
                                         c_double_p]),

@@ -291,6 +291,27 @@ def carrier_correct_post_SCH(s, pos_info, oversampling_ratio, carrier_freq, ctx=
     return rr, cp.value
 
 
+def SCH_equalise(s, pos_info, training_sequence, oversampling_ratio, ctx=None):
+    """Front end of SCH_demod(s, pos_info, training_sequence, ov) -- SCH_demod.m:53-59,79-90: the equalised burst of
+    every SCH row of pos_info, shape (num_sch, 194*ov).  pos_info all -1 (:8-11) -> None."""
+    ctx = ctx or default_context()
+    buf, n = _r_in(s)
+    pi = np.atleast_2d(np.asarray(pos_info, dtype=np.float64))
+    rows = pi.shape[0]
+    pic = np.ascontiguousarray(pi.T)
+    ts = np.ascontiguousarray(np.asarray(training_sequence, dtype=np.complex128).ravel())
+    L = 194 * int(oversampling_ratio)
+    cap = int(np.sum(pi[:, 1] == 1)) if pi.shape[1] > 1 else 0
+    out = np.empty((max(cap, 1), L), dtype=np.complex128)
+    nb, lf = C.c_int(), C.c_int()
+    rc = ctx.check(ctx.lib.gsmcal_SCH_equalise(ctx.h, _dp(buf) if buf is not None else None, n, _dp(pic), rows, rows, _dp(ts),
+                                               len(ts), int(oversampling_ratio), _dp(out), cap, C.byref(nb), C.byref(lf)),
+                   "SCH_equalise")
+    if rc == 10:
+        return None
+    return out[:nb.value]
+
+
 def total_ppm_calculation(ppm_in):
     lib = _lib.load()
     p = np.ascontiguousarray(np.atleast_1d(np.asarray(ppm_in, dtype=np.float64)))

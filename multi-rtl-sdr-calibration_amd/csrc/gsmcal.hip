@@ -23,6 +23,7 @@
 #include "kernels_detect.h"
 #include "kernels_estim.h"
 #include "kernels_frontend.h"
+#include "kernels_demod.h"
 #include "state.h"
 
 #define GSMCAL_VERSION "gsmcal-mi355x 0.1 (gfx950)"
@@ -84,7 +85,8 @@ struct gsmcal_ctx {
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     // shared workspace
-    DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, csum_head;
+    DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, csum_head, tw_sch;
+    int tw_sch_n = 0;                        // length the SCH-demodulator twiddle table was built for
     std::vector<double> h_head;              // partial tap sums uploaded to csum_head (see coarse())
     unsigned long coef_epoch = 0, head_epoch = ~0ul;   // coef_epoch: bumped whenever h_coef changes
     int tw_n = 0;                            // length the twiddle table was built for
@@ -744,6 +746,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sch_equalise, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sch_fd_training, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipGetLastError();   // an attribute request the device rejects must not surface at the first launch
@@ -790,7 +794,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->coef, &c->ts, &c->cf, &c->table, &c->snrhit, &c->arr_in, &c->arr_out, &c->posinfo, &c->rlen,
-                      &c->misc, &c->tw, &c->csum_head};
+                      &c->misc, &c->tw, &c->csum_head, &c->tw_sch};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
@@ -1172,6 +1176,56 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, co
         RET_IF(materialise_to_host(c, src, 1, lr, r));
     }
     return positive_status(st, 2);
+}
+
+// ---- f4 SCH demodulator front end -------------------------------------------------------------------------
+int gsmcal_SCH_equalise(gsmcal_ctx* c, const double* s, long len, const double* pos_info, int rows, int ld, const double* sch_ts,
+                        int len_ts, int ov, double* x_eq, int cap_bursts, int* num_bursts, int* len_fde_ov) {
+    if (!c || !pos_info || !sch_ts || !num_bursts || rows < 1 || ld < rows || ov < 1 || len_ts < 1 || cap_bursts < 0) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int L = (148 + 2 * 8 + 30) * ov, N2 = L / DM_N1;      // SCH_demod.m:22,45,53-55: round(156.25 - 8.25) + 2*8 + 30 symbols
+    const int sp_t0 = (8 + 42) * ov;                            // :56 sp_of_training (0-based)
+    *num_bursts = 0;
+    if (len_fde_ov) *len_fde_ov = L;
+    bool all_m1 = true;                                         // :8 `if pos_info == -1`: every element
+    for (int i = 0; i < rows; ++i) all_m1 = all_m1 && pos_info[i] == -1.0 && pos_info[ld + i] == -1.0;
+    if (all_m1) return GSMCAL_S_POST_NO_POS;
+    if (!s || len < 1 || !x_eq) return GSMCAL_E_ARG;
+    if (sp_t0 + len_ts > L) return GSMCAL_E_ARG;                // the training sequence must fit the window (:58)
+    std::vector<long> starts;
+    for (int i = 0; i < rows; ++i)
+        if (pos_info[ld + i] == 1.0) starts.push_back((long)pos_info[i] - 8L * ov - 1);   // :13-14, :79 (0-based)
+    const int nb = (int)starts.size();
+    if (nb == 0) return 0;
+    if (nb > cap_bursts) return GSMCAL_E_CAPACITY;
+    const size_t lds = dm_lds_bytes(L, N2);
+    if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
+    c->cur = &c->lanes[0];
+    RET_IF(upload_array(c, s, (size_t)len));
+    RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
+    if (c->tw_sch_n != L) {
+        RET_IF(ensure(c, c->tw_sch, (size_t)L * sizeof(cplx)));
+        LAUNCH(c, k_make_twiddles, dim3((L + 255) / 256), dim3(256), 0, (cplx*)c->tw_sch.p, L);
+        c->tw_sch_n = L;
+    }
+    RET_IF(ensure(c, c->misc, (size_t)nb * (sizeof(long) + sizeof(int)) + (size_t)L * sizeof(cplx) + 64));
+    cplx* d_ft = (cplx*)c->misc.p;
+    long* d_start = (long*)(d_ft + L);
+    int* d_status = (int*)(d_start + nb);
+    RET_IF(ensure(c, c->arr_out, (size_t)nb * L * sizeof(cplx)));
+    HIPCHK(c, hipMemcpyAsync(d_start, starts.data(), (size_t)nb * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, k_sch_fd_training, dim3(1), dim3(DM_THREADS), lds, (const cplx*)c->ts.p, len_ts, sp_t0, L, N2, (const cplx*)c->tw_sch.p, d_ft);
+    LAUNCH(c, k_sch_equalise, dim3(nb), dim3(DM_THREADS), lds, (const cplx*)c->arr_in.p, len, (const long*)d_start, len_ts, sp_t0, L, N2,
+           (const cplx*)c->tw_sch.p, (const cplx*)d_ft, (cplx*)c->arr_out.p, d_status);
+    CHECK_LAUNCH(c);
+    std::vector<int> st(nb);
+    HIPCHK(c, hipMemcpyAsync(st.data(), d_status, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(x_eq, c->arr_out.p, (size_t)nb * L * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nb; ++i)
+        if (st[i] != 0) return st[i];                           // MATLAB: index exceeds matrix dimensions at s(sp:ep), :81
+    *num_bursts = nb;
+    return 0;
 }
 
 // ---- a9 total_ppm_calculation ---------------------------------------------------------------------------

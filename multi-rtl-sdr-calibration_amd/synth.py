@@ -171,8 +171,10 @@ def ideal_waveform(num_frames, start_frame, rng, bcch=True):
 
 def make_stream(dongle=0, arfcn=0, num_frames=102, seed=DEFAULT_SEED, bcch=True,
                 sampling_ppm=None, carrier_ppm=None, snr_db=None, carrier_freq=957.4e6,
-                start_frame=None, frac_start=None):
-    """One capture: returns (raw uint8 interleaved I,Q of length 2*num_frames*10000, truth dict)."""
+                start_frame=None, frac_start=None, tx_key=None):
+    """One capture: returns (raw uint8 interleaved I,Q of length 2*num_frames*10000, truth dict).
+    tx_key: dongles given the same key receive the SAME transmission (payload, multiframe phase, start instant) through
+    their own clocks, carrier offsets and noise -- what gsm_sync_demod.m's inter-dongle phase plot (:151-158) looks at."""
     rng = np.random.Generator(np.random.Philox(key=[int(seed), (int(dongle) << 20) ^ int(arfcn)]))
     eps_s = rng.uniform(-80.0, 80.0) if sampling_ppm is None else float(sampling_ppm)
     eps_c = rng.uniform(-40.0, 40.0) if carrier_ppm is None else float(carrier_ppm)
@@ -180,7 +182,15 @@ def make_stream(dongle=0, arfcn=0, num_frames=102, seed=DEFAULT_SEED, bcch=True,
     sf = int(rng.integers(0, 51)) if start_frame is None else int(start_frame)
     fs0 = rng.uniform(0.0, FRAME_OV) if frac_start is None else float(frac_start)
     n = num_frames * FRAME_OV
-    ideal = ideal_waveform(num_frames + 2, sf, rng, bcch=bcch)
+    if tx_key is None:
+        ideal = ideal_waveform(num_frames + 2, sf, rng, bcch=bcch)
+    else:
+        txr = np.random.Generator(np.random.Philox(key=[int(seed) ^ 0x5A5A5A5A, int(tx_key)]))
+        if start_frame is None:
+            sf = int(txr.integers(0, 51))
+        if frac_start is None:
+            fs0 = txr.uniform(0.0, FRAME_OV)
+        ideal = ideal_waveform(num_frames + 2, sf, txr, bcch=bcch)
     # the dongle's clock runs (1+eps_s) fast => sample k is taken at ideal time k/(1+eps_s)... the
     # estimator's sign convention (FCCH_fine_correction.m:111-115): observed spacing = ideal*(1+e)
     # means the dongle takes MORE samples per GSM frame, i.e. query ideal time t_k = k/(1+e).

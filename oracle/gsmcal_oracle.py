@@ -550,6 +550,42 @@ def carrier_correct_post_SCH(s, pos_info, oversampling_ratio, carrier_freq, info
 
 
 # ------------------------------------------------------------------------------------------------
+# f4  front end of SCH_demod.m (:53-59, :79-90) -- the equalised SCH bursts; the Viterbi demodulator is out of scope
+# ------------------------------------------------------------------------------------------------
+def SCH_equalise(s, pos_info, training_sequence, oversampling_ratio):
+    """Returns (num_sch, len_fde_ov) complex: x after :90 for every SCH row of pos_info; None when pos_info == -1 (:8-11)."""
+    pos_info = np.atleast_2d(np.asarray(pos_info, dtype=np.float64))
+    if np.all(pos_info == -1):  # :8
+        return None
+    s = np.asarray(s).ravel()
+    ts = np.asarray(training_sequence).ravel()
+    sch_pos = pos_info[pos_info[:, 1] == 1, 0]  # :13-14
+    num_sym_per_slot = 625.0 / 4.0
+    num_ef_sym_per_slot = int(matlab_round(num_sym_per_slot - 8.25))  # :22
+    len_ts_ov = 64 * oversampling_ratio
+    len_pre_ts = 42
+    traceback = 30  # :45
+    ex_len = 8  # :53
+    len_fde_ov = (num_ef_sym_per_slot + 2 * ex_len + traceback) * oversampling_ratio  # :54-55
+    sp_t = (ex_len + len_pre_ts) * oversampling_ratio + 1  # :56 (1-based)
+    td = np.zeros(len_fde_ov, dtype=np.complex128)
+    td[sp_t - 1:sp_t - 1 + len_ts_ov] = ts  # :57-58
+    fd_training = np.fft.fft(td)  # :59
+    out = np.zeros((len(sch_pos), len_fde_ov), dtype=np.complex128)
+    for i, p in enumerate(sch_pos):
+        sp = int(p) - ex_len * oversampling_ratio  # :79
+        ep = sp + len_fde_ov - 1
+        if sp < 1 or ep > len(s):
+            raise MatlabIndexError("SCH burst window outside the signal")
+        x = s[sp - 1:ep]  # :81
+        rt = np.zeros(len_fde_ov, dtype=np.complex128)
+        rt[sp_t - 1:sp_t - 1 + len_ts_ov] = x[sp_t - 1:sp_t - 1 + len_ts_ov]  # :83-84
+        fd_chn = np.fft.fft(rt) / fd_training  # :85-86
+        out[i] = np.fft.ifft(np.fft.fft(x) / fd_chn)  # :88-90
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # a9  total_ppm_calculation.m:5-21
 # ------------------------------------------------------------------------------------------------
 def total_ppm_calculation(ppm_in):
@@ -592,6 +628,31 @@ def calibrate_stream(raw, coef, sch_training_sequence, carrier_freq,
     if keep_r:
         out["r_correct"] = r_c
     return out
+
+
+def burst_map(pos_info, oversampling_ratio=8):
+    """gsm_sync_demod.m:130-134: a = NaN(1, max(round(pos./frame))); a(round(pos(type==k)./frame)) = k for k = 0, 1, 2."""
+    pos_info = np.atleast_2d(np.asarray(pos_info, dtype=np.float64))
+    frame = (625.0 / 4.0) * 8 * oversampling_ratio
+    idx = matlab_round(pos_info[:, 0] / frame).astype(np.int64)
+    a = np.full(int(np.max(idx)), np.nan)
+    for k in (0.0, 1.0, 2.0):
+        a[idx[pos_info[:, 1] == k] - 1] = k
+    return a
+
+
+def sampling_phase_difference(pos_info_1, pos_info_2, oversampling_ratio=8):
+    """gsm_sync_demod.m:151-156 (num_dongle == 2): [num_pos, min_idx] = min(num_pos); the first num_pos burst starts of both
+    dongles, their difference pos_tmp2 - pos_tmp1 and the x axis round(pos_tmp(:,1)./frame) of the shorter table
+    (the reference indexes that x axis with ALL rows of the shorter table: equal to num_pos by construction)."""
+    p1 = np.atleast_2d(np.asarray(pos_info_1, dtype=np.float64))
+    p2 = np.atleast_2d(np.asarray(pos_info_2, dtype=np.float64))
+    num_pos = [len(p1), len(p2)]
+    n = min(num_pos)
+    min_idx = int(np.argmin(num_pos))  # first minimum, like MATLAB's min
+    frame = (625.0 / 4.0) * 8 * oversampling_ratio
+    x = matlab_round((p1, p2)[min_idx][:, 0] / frame)
+    return x, p2[:n, 0] - p1[:n, 0]
 
 
 def scanner_accept(FCCH_pos, FCCH_snr):

@@ -536,3 +536,64 @@ def test_native_allgather_of_the_table_single_rank(g, ctx, setup, tmp_path):
                 comm.close()
     finally:
         ctx.free(d_loc); ctx.free(d_all)
+
+
+def test_SCH_equalise_front_end_of_the_demodulator(g, setup):
+    """SURVEY 8f-4, SCH_demod.m:53-59,79-90: equalised SCH bursts (three 1552-point transforms and two spectral divisions per
+    burst) from a really calibrated stream, against the oracle; plus the reference's early exit and index error."""
+    raw = np.stack([g.synth.make_stream(dongle=d)[0] for d in (0, 3)])
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, want_r=True)
+    done = 0
+    for i in range(2):
+        if out["table"][i, 9] != 0:
+            continue
+        L = int(out["r_len"][i])
+        r = out["r_correct"][i, :L]
+        pi = out["pos_info"][i]
+        want = o.SCH_equalise(r, pi, setup["ts"], 8)
+        got = g.SCH_equalise(r, pi, setup["ts"], 8)
+        assert got.shape == want.shape == (int(np.sum(pi[:, 1] == 1)), 1552)
+        assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(want))
+        done += 1
+        # index error where MATLAB's s(sp:ep) would run past the stream
+        with pytest.raises(g.GsmcalError):
+            g.SCH_equalise(r[: int(pi[pi[:, 1] == 1, 0][-1]) + 100], pi, setup["ts"], 8)
+    assert done >= 1
+    assert g.SCH_equalise(-1.0, np.array([[-1.0, -1.0]]), setup["ts"], 8) is None and \
+        o.SCH_equalise(-1.0, np.array([[-1.0, -1.0]]), setup["ts"], 8) is None
+    # other oversampling ratio: 776 = 97 x 8 points
+    r4 = np.ascontiguousarray(out["r_correct"][0, : int(out["r_len"][0]) : 2]) if out["table"][0, 9] == 0 else None
+    if r4 is not None:
+        pi4 = out["pos_info"][0].copy()
+        pi4[:, 0] = np.floor((pi4[:, 0] - 1) / 2) + 1
+        ts4 = np.ascontiguousarray(setup["ts"][0::2])
+        want = o.SCH_equalise(r4, pi4, ts4, 4)
+        got = g.SCH_equalise(r4, pi4, ts4, 4)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(want))
+
+
+def test_inter_dongle_phase_difference_from_gathered_pos_info(g, setup):
+    """SURVEY 8f-2, gsm_sync_demod.m:130-134,151-158: two dongles hear the same transmission through their own clocks;
+    the burst map and the sampling-phase difference are computed from the pos_info tables the GPU chain produced, and
+    compared with the oracle's restatement evaluated on the oracle's own tables."""
+    from gsmcal import dist as gd
+    tried = 0
+    for key in range(40, 60):
+        raw = np.stack([g.synth.make_stream(dongle=900 + key * 2 + j, tx_key=key)[0] for j in range(2)])
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+        if np.any(out["table"][:, 9] != 0):
+            continue                                               # a stream the reference algorithm rejects: next pair
+        tried += 1
+        orc = [o.calibrate_stream(raw[j], setup["coef"], setup["ts"], FC) for j in range(2)]
+        for j in range(2):
+            parity.assert_positions(out["pos_info"][j], orc[j]["pos_info"], f"pos_info dongle {j}")
+            assert np.array_equal(gd.burst_map(out["pos_info"][j]), o.burst_map(orc[j]["pos_info"]), equal_nan=True)
+        x, dphi = o.sampling_phase_difference(orc[0]["pos_info"], orc[1]["pos_info"])
+        assert np.array_equal(gd.sampling_phase_difference(out["pos_info"][0], out["pos_info"][1]), dphi)
+        assert np.array_equal(gd.sampling_phase_frames(out["pos_info"][0], out["pos_info"][1]), x)
+        # same transmission: every compared burst is the same burst, so the difference is constant to within the
+        # +-1 sample of the two independent position estimates
+        assert np.max(dphi) - np.min(dphi) <= 2
+        if tried == 2:
+            break
+    assert tried >= 1
