@@ -75,6 +75,30 @@ enum {
     GSMCAL_T_STATUS = 9             /* first non-zero status code met along the chain               */
 };
 
+/* ---- algorithm thresholds (the constants the reference hard-codes inside its functions) ---------- */
+/* Defaults = the reference's literals.  gsmcal_set_params() takes effect from the next call on; the fields marked
+ * "geometry" size windows and launch shapes and must keep their default (any other value: GSMCAL_E_UNSUPPORTED). */
+typedef struct gsmcal_params {
+    double coarse_th_db;        /* FCCH_coarse_position.m:21          th = 10            hit iff snr - avg > th            */
+    int coarse_mv_factor;       /* FCCH_coarse_position.m:22          mv_len = 10*fft_len                     (geometry)  */
+    int coarse_max_offset;      /* FCCH_coarse_position.m:45          max_offset = 5                          (geometry)  */
+    int min_hits;               /* FCCH_fine_correction.m:12,69,142; SCH_corr_rate_correction.m:11,84        5            */
+    int fine_max_offset;        /* FCCH_fine_correction.m:30          max_offset = 64 symbols                 (geometry)  */
+    double fine_max_ppm;        /* FCCH_fine_correction.m:83          max_ppm = 4000     spacing classes                  */
+    double fine_gate_snr_db;    /* FCCH_fine_correction.m:192         FCCH_snr < 5  ->  FCCH_pos = -1                     */
+    double fine_noise_bw_hz;    /* FCCH_fine_correction.m:22          200e3: half_noise_len                   (geometry)  */
+    int sch_max_offset;         /* SCH_corr_rate_correction.m:36      max_offset = 8 symbols                  (geometry)  */
+    double sch_max_ppm;         /* SCH_corr_rate_correction.m:94      max_ppm = 400                                       */
+    int post_min_bcch;          /* carrier_correct_post_SCH.m:15      fewer than 4 BCCH rows -> r = -1                    */
+    int scan_min_hits;          /* multi_rtl_sdr_gsm_FCCH_scanner.m:169  at least 3 hits                                  */
+    double scan_spacing;        /* ..FCCH_scanner.m:171               12500 (1x symbols between FCCH bursts)              */
+    double scan_spacing_idle;   /* ..FCCH_scanner.m:176               12500 + 1250 across the idle frame                  */
+    double scan_tol;            /* ..FCCH_scanner.m:171,176           50                                                  */
+} gsmcal_params;
+void gsmcal_params_default(gsmcal_params* p);
+int gsmcal_set_params(gsmcal_ctx* ctx, const gsmcal_params* p);
+int gsmcal_get_params(gsmcal_ctx* ctx, gsmcal_params* p);
+
 /* ---- context --------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device_id` with its own non-blocking HIP stream. */
 int gsmcal_ctx_create(int device_id, gsmcal_ctx** out);

@@ -87,6 +87,22 @@ SIGNATURES = {
 }
 
 
+class Params(C.Structure):
+    """gsmcal_params of include/gsmcal.h (field order and types must match)."""
+    _fields_ = [("coarse_th_db", C.c_double), ("coarse_mv_factor", C.c_int), ("coarse_max_offset", C.c_int),
+                ("min_hits", C.c_int), ("fine_max_offset", C.c_int), ("fine_max_ppm", C.c_double),
+                ("fine_gate_snr_db", C.c_double), ("fine_noise_bw_hz", C.c_double), ("sch_max_offset", C.c_int),
+                ("sch_max_ppm", C.c_double), ("post_min_bcch", C.c_int), ("scan_min_hits", C.c_int),
+                ("scan_spacing", C.c_double), ("scan_spacing_idle", C.c_double), ("scan_tol", C.c_double)]
+
+
+SIGNATURES.update({
+    "gsmcal_params_default": (None, [C.POINTER(Params)]),
+    "gsmcal_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "gsmcal_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+})
+
+
 class GsmcalError(RuntimeError):
     pass
 

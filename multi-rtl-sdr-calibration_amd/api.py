@@ -67,6 +67,20 @@ class Context:
     def sync(self):
         self.check(self.lib.gsmcal_sync(self.h), "gsmcal_sync")
 
+    # ---- thresholds (gsmcal_params: the constants the reference hard-codes) ----
+    def get_params(self):
+        p = _lib.Params()
+        self.check(self.lib.gsmcal_get_params(self.h, C.byref(p)), "gsmcal_get_params")
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(f"gsmcal_params has no field {k}")
+            setattr(p, k, v)
+        self.check(self.lib.gsmcal_set_params(self.h, C.byref(p)), "gsmcal_set_params")
+
     # ---- device memory ----
     def alloc(self, nbytes):
         p = C.c_void_p()

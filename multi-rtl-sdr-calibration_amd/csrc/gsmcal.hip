@@ -84,6 +84,8 @@ struct gsmcal_ctx {
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
+    gsmcal_params params;           // thresholds (defaults = the reference's literals)
+    unsigned long params_epoch = 0; // bumped by gsmcal_set_params: captured graphs carry the old values
     // shared workspace
     DevBuf coef, ts, cf, table, snrhit, arr_in, arr_out, posinfo, rlen, misc, tw, csum_head, tw_sch;
     int tw_sch_n = 0;                        // length the SCH-demodulator twiddle table was built for
@@ -295,9 +297,20 @@ int make_tail(gsmcal_ctx* c, int S, const StepArgs& sa, int steps, int lvl_a, in
     return 0;
 }
 
+DevParams dev_params(const gsmcal_ctx* c) {
+    DevParams P;
+    memset(&P, 0, sizeof(P));
+    P.coarse_th = c->params.coarse_th_db; P.fine_max_ppm = c->params.fine_max_ppm; P.fine_gate_snr = c->params.fine_gate_snr_db;
+    P.sch_max_ppm = c->params.sch_max_ppm; P.scan_spacing = c->params.scan_spacing; P.scan_spacing_idle = c->params.scan_spacing_idle;
+    P.scan_tol = c->params.scan_tol; P.min_hits = c->params.min_hits; P.post_min_bcch = c->params.post_min_bcch;
+    P.scan_min_hits = c->params.scan_min_hits;
+    return P;
+}
+
 StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
     StepArgs a;
     memset(&a, 0, sizeof(a));
+    a.P = dev_params(c);
     a.ov = g.ov; a.H = H; a.NB = g.NB; a.len_ts = len_ts;
     a.peaks = (const PeakOut*)c->cur->peaks.p;
     a.carrier_freq = c->cf_lane ? c->cf_lane : (const double*)c->cf.p;
@@ -547,6 +560,7 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
         a.n_head = n_head;
     }
     a.s = d_dec; a.s_stride = stride; a.len = len; a.decimation_ratio = dec_ratio; a.mode = 0;
+    a.th0 = c->params.coarse_th_db; a.min_hits = c->params.min_hits;
     a.fine_setup_ov = fine_setup_ov;
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
@@ -722,6 +736,35 @@ extern "C" {
 
 const char* gsmcal_version(void) { return GSMCAL_VERSION; }
 
+void gsmcal_params_default(gsmcal_params* p) {
+    if (!p) return;
+    p->coarse_th_db = 10.0; p->coarse_mv_factor = 10; p->coarse_max_offset = 5; p->min_hits = 5;
+    p->fine_max_offset = 64; p->fine_max_ppm = 4000.0; p->fine_gate_snr_db = 5.0; p->fine_noise_bw_hz = 200e3;
+    p->sch_max_offset = 8; p->sch_max_ppm = 400.0; p->post_min_bcch = 4;
+    p->scan_min_hits = 3; p->scan_spacing = 12500.0; p->scan_spacing_idle = 12500.0 + 1250.0; p->scan_tol = 50.0;
+}
+
+int gsmcal_set_params(gsmcal_ctx* c, const gsmcal_params* p) {
+    if (!c || !p) return GSMCAL_E_ARG;
+    gsmcal_params d;
+    gsmcal_params_default(&d);
+    if (p->coarse_mv_factor != d.coarse_mv_factor || p->coarse_max_offset != d.coarse_max_offset ||
+        p->fine_max_offset != d.fine_max_offset || p->fine_noise_bw_hz != d.fine_noise_bw_hz || p->sch_max_offset != d.sch_max_offset) {
+        c->err = "gsmcal_set_params: a geometry field differs from its default";
+        return GSMCAL_E_UNSUPPORTED;
+    }
+    if (p->min_hits < 2 || p->min_hits > GSMCAL_MAX_HITS || p->scan_min_hits < 1 || p->post_min_bcch < 0) return GSMCAL_E_ARG;
+    c->params = *p;
+    ++c->params_epoch;
+    return 0;
+}
+
+int gsmcal_get_params(gsmcal_ctx* c, gsmcal_params* p) {
+    if (!c || !p) return GSMCAL_E_ARG;
+    *p = c->params;
+    return 0;
+}
+
 int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** out) {
     if (!out) return GSMCAL_E_ARG;
     *out = nullptr;
@@ -752,6 +795,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipGetLastError();   // an attribute request the device rejects must not surface at the first launch
     gsmcal_ctx* c = new gsmcal_ctx();
+    gsmcal_params_default(&c->params);
     c->device = device_id;
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
@@ -957,6 +1001,7 @@ static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, St
     RET_IF(push_states(c, v));
     c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     a.s = (const cplx*)c->arr_in.p; a.s_stride = len; a.len = len;
+    a.th0 = c->params.coarse_th_db; a.min_hits = c->params.min_hits;
     int fft_len = a.fft_len;
     long n_first = len;
     if (a.mode == 0) {
@@ -1283,7 +1328,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
                                         (uintptr_t)d_snr_numhit, (uintptr_t)d_positions, (uintptr_t)d_pos_snr,
-                                        (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg};
+                                        (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg, (uintptr_t)c->params_epoch};
     auto enqueue = [&]() -> int {
     const int nl = plan_lanes(c, d, false);
     RET_IF(fork_lanes(c, nl));
@@ -1302,6 +1347,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
+        sa.P = dev_params(c);
         sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
         sa.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
         sa.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
@@ -1361,7 +1407,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     // compute-bound fine search of another; a repeated call is replayed as one hipGraph
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps, (uintptr_t)len_ts,
                                         (uintptr_t)d_table, (uintptr_t)d_pos_info, (uintptr_t)d_r_correct,
-                                        (uintptr_t)d_r_len, (uintptr_t)c->n_lanes_cfg};
+                                        (uintptr_t)d_r_len, (uintptr_t)c->n_lanes_cfg, (uintptr_t)c->params_epoch};
     auto enqueue = [&]() -> int {
     const int nl = plan_lanes(c, d);
     RET_IF(fork_lanes(c, nl));

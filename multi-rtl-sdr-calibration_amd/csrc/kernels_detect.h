@@ -162,6 +162,7 @@ struct CoarseArgs {
     double csum_all;                          // mean_corr: the input is the FIR of the raw bytes; remove mean*csum on load
     const double* csum_head; int n_head;      //            partial tap sums of the rows that overlap filter()'s zero initial state
     int mean_corr;
+    double th0; int min_hits;                 // mode 0: gsmcal_params.coarse_th_db (FCCH_coarse_position.m:21), min_hits for the fine setup
     const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
     int npartial; long n0;                    //            and the capture length they divide by
 };
@@ -205,7 +206,7 @@ __device__ __forceinline__ CoarseGeom coarse_geom(const CoarseArgs& a) {
     if (a.mode == 0) {
         // FCCH_coarse_position.m:15-25
         g.fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
-        g.th = 10.0;
+        g.th = a.th0;
         g.mv_len = 10 * g.fft_len;
         g.n_first = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
     } else {
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
 
-__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl);   // kernels_estim.h
+__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl, int min_hits);   // kernels_estim.h
 
 // ---- k_coarse_scan: first hit + hop walk of FCCH_coarse_position, one workgroup per stream ----
 // grid S, block 256.  LDS: state copy | 64 twiddles | 4 x 36 hop samples | 2 x 11 x 17 hop powers | snr[mv_len + nwin + 64].
@@ -725,7 +726,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         }
     }
     __syncthreads();
-    if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0);
+    if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0, a.min_hits);
     __syncthreads();
     CS_STAMP(5);
     {

@@ -330,12 +330,12 @@ __device__ __forceinline__ void fine_sentinel(StreamState* st) {
 }
 
 // FCCH_fine_correction.m:8-46 -- window list for the fine search (level `lvl`)
-__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl) {
+__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl, int min_hits) {
     (void)s;
     fine_sentinel(st);
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
     if (st->status < 0) return;
-    if (st->n_coarse < 5) { set_status(st, 0, GSMCAL_S_FEW_HITS); return; }   // :12
+    if (st->n_coarse < min_hits) { set_status(st, 0, GSMCAL_S_FEW_HITS); return; }   // :12
     const long len_s_ov = level_len(st, lvl);
     const long len_s = len_s_ov / ov;                                          // :28
     const int max_offset = 64, len_cw = 148;
@@ -351,7 +351,7 @@ __device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl) {
 }
 
 // FCCH_fine_correction.m:52-137 -- positions, sampling error, new grid, burst windows at level lvl+1
-__device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int H, int NB, int ov, int lvl) {
+__device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int H, int NB, int ov, int lvl, const DevParams& P) {
     (void)s;
     if (st->status < 0 || st->stage_status[0] != 0) { st->n_win = 0; return; }
     const int last_idx = st->n_win;        // fine_first[0..last_idx) was filled by the lanes of k_step
@@ -359,7 +359,7 @@ __device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int 
     st->n_fine = last_idx;
     st->n_win = 0;
     const int fft_len = 148 * ov;
-    if (last_idx < 5) {                                                        // :69 not taken
+    if (last_idx < P.min_hits) {                                               // :69 not taken
         st->fcch_is_sentinel = 0;
         st->n_fcch = last_idx;
         for (int w = 0; w < last_idx; ++w) st->fcch_pos[w] = st->fine_first[w];
@@ -367,7 +367,7 @@ __device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int 
         return;
     }
     const double d_ov = 10.0 * 1250.0 * (double)ov, d1_ov = 11.0 * 1250.0 * (double)ov;   // :80-81
-    const double max_ppm = 4000.0;
+    const double max_ppm = P.fine_max_ppm;                                                 // :83
     const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
     int na = 0, nb = 0;
     double expected = 0.0;
@@ -407,7 +407,7 @@ __device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int 
     if (st->fcch_pos[n - 1] + (double)fft_len - 1.0 > (double)max_len) --n;  // :135
     st->n_fcch = n;
     st->fcch_is_sentinel = 0;
-    if (n >= 5) {                                                              // :142
+    if (n >= P.min_hits) {                                                     // :142
         for (int i = 0; i < n; ++i) {
             const long sp = (long)st->fcch_pos[i];
             if (sp < 1 || sp + fft_len - 1 > max_len) { set_status(st, 0, GSMCAL_E_INDEX); return; }
@@ -437,7 +437,7 @@ __device__ __forceinline__ double carrier_from_bursts(StreamState* st, int nb, i
 }
 
 // FCCH_fine_correction.m:158-165,192-196
-__device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl) {
+__device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl, const DevParams& P) {
     (void)s;
     const int nb = st->n_win;
     st->n_win = 0;
@@ -445,7 +445,7 @@ __device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* c
     carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 2, st->op[lvl + 1].n, &st->carrier_ppm1);
     st->r1_kind = 3;
     int low = 0;
-    for (int i = 0; i < nb; ++i) low += st->snr_burst[i] < 5.0;
+    for (int i = 0; i < nb; ++i) low += st->snr_burst[i] < P.fine_gate_snr;
     if (low > 0) {                                                             // :192
         st->n_fcch = 0;
         st->fcch_is_sentinel = 1;
@@ -454,14 +454,14 @@ __device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* c
 }
 
 // SCH_corr_rate_correction.m:8-48 -- correlation windows at level lvl
-__device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl) {
+__device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl, const DevParams& P) {
     (void)s;
     st->sch_edge = 0;
     st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0; st->n_sent_rows = 1;   // :9 pos_info = [-1, -1]
     st->sampling_ppm2 = INFINITY; st->r2_kind = 0;
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
     if (st->status < 0) return;
-    if (st->fcch_is_sentinel || st->n_fcch < 5) { set_status(st, 1, GSMCAL_S_FEW_HITS); return; }  // :11
+    if (st->fcch_is_sentinel || st->n_fcch < P.min_hits) { set_status(st, 1, GSMCAL_S_FEW_HITS); return; }  // :11
     const long len_s_ov = level_len(st, lvl);
     const long fix_off = (long)((1250 + 42) * ov);       // :26-27
     const long max_offset = 8 * ov;                      // :36
@@ -477,7 +477,7 @@ __device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl)
 }
 
 // SCH_corr_rate_correction.m:59-181
-__device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl) {
+__device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl, const DevParams& P) {
     (void)s;
     const int num_sch = st->n_win;
     st->n_win = 0;
@@ -485,10 +485,10 @@ __device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl) {
     st->n_sch_first = num_sch;
     if (st->sch_edge) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63 pos_info = [-1, -1]
     st->n_sent_rows = 3 * st->n_fcch;                                          // :32 pos_info = -ones(3*num_fcch_hit, 2) from here on
-    if (num_sch < 5) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }          // :84
+    if (num_sch < P.min_hits) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }   // :84
     const double frame_ov = 1250.0 * (double)ov, slot_ov = 156.25 * (double)ov;
     const double d_ov = 10.0 * frame_ov, d1_ov = 11.0 * frame_ov;
-    const double max_ppm = 400.0;
+    const double max_ppm = P.sch_max_ppm;                                                  // :94
     const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
     int na = 0, nb = 0;
     unsigned a_mask = 0, b_mask = 0;
@@ -567,7 +567,7 @@ __device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl) {
 }
 
 // carrier_correct_post_SCH.m:8-62 -- FCCH-row windows at level lvl
-__device__ void d_post_setup(StreamState* st, int s, int ov, int lvl) {
+__device__ void d_post_setup(StreamState* st, int s, int ov, int lvl, const DevParams& P) {
     (void)s;
     st->n_win = 0; st->carrier_ppm2 = INFINITY; st->r3_kind = 0;
     for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
@@ -577,7 +577,7 @@ __device__ void d_post_setup(StreamState* st, int s, int ov, int lvl) {
     const double* pi1 = st->pos_info + MAXROWS;
     int nb = 0;
     for (int i = 0; i < st->n_rows; ++i) nb += pi1[i] == 2.0;
-    if (nb < 4) { set_status(st, 2, GSMCAL_S_POST_FEW_BCCH); return; }         // :15-19
+    if (nb < P.post_min_bcch) { set_status(st, 2, GSMCAL_S_POST_FEW_BCCH); return; }   // :15-19
     const int fft_len = 148 * ov;
     const long len = level_len(st, lvl);
     int cnt = 0;
@@ -629,14 +629,14 @@ __device__ void d_totals(const StreamState* st, int s, double* table, double* po
 
 // multi_rtl_sdr_gsm_FCCH_scanner.m:168-185 acceptance -> (snr, num_hit) per capture
 __device__ void d_scan_accept(const StreamState* st, int s, double* snr_numhit, double* positions,
-                              double* pos_snr, int* counts) {
+                              double* pos_snr, int* counts, const DevParams& P) {
     const int n = st->n_coarse;
     double snr = 0.0, num_hit = 0.0;
-    if (n >= 3) {
+    if (n >= P.scan_min_hits) {
         bool ok = true;
         for (int i = 0; i < n - 1 && ok; ++i) {
             const double d = st->coarse_pos[i + 1] - st->coarse_pos[i];
-            if (fabs(d - 12500.0) > 50.0) ok = !(fabs(d - (12500.0 + 1250.0)) > 50.0);
+            if (fabs(d - P.scan_spacing) > P.scan_tol) ok = !(fabs(d - P.scan_spacing_idle) > P.scan_tol);
         }
         if (ok) {
             double sum = 0.0;
@@ -680,6 +680,7 @@ struct StepArgs {
     const double* carrier_freq;
     double* table; double* pos_info_out; long* r_len_out;
     double* snr_numhit; double* positions; double* pos_snr; int* counts;
+    DevParams P;
 };
 
 enum { STEP_FINE_SETUP = 1, STEP_FINE_DECIDE = 2, STEP_CARRIER_DECIDE = 4, STEP_SCH_SETUP = 8, STEP_SCH_DECIDE = 16,
@@ -713,15 +714,15 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
     if (steps & STEP_FINE_DECIDE) __syncthreads();
     TAIL_STAMP(10);
     if (lane == 0) {
-        if (steps & STEP_FINE_SETUP) d_fine_setup(sh, s, a.ov, lvl_a);
-        if (steps & STEP_FINE_DECIDE) d_fine_decide(sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a);
-        if (steps & STEP_CARRIER_DECIDE) d_carrier_decide(sh, s, a.ov, a.carrier_freq, lvl_a);
-        if (steps & STEP_SCH_SETUP) d_sch_setup(sh, s, a.ov, a.len_ts, lvl_b);
-        if (steps & STEP_SCH_DECIDE) d_sch_decide(sh, s, a.ov, lvl_a);
-        if (steps & STEP_POST_SETUP) d_post_setup(sh, s, a.ov, lvl_b);
+        if (steps & STEP_FINE_SETUP) d_fine_setup(sh, s, a.ov, lvl_a, a.P.min_hits);
+        if (steps & STEP_FINE_DECIDE) d_fine_decide(sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a, a.P);
+        if (steps & STEP_CARRIER_DECIDE) d_carrier_decide(sh, s, a.ov, a.carrier_freq, lvl_a, a.P);
+        if (steps & STEP_SCH_SETUP) d_sch_setup(sh, s, a.ov, a.len_ts, lvl_b, a.P);
+        if (steps & STEP_SCH_DECIDE) d_sch_decide(sh, s, a.ov, lvl_a, a.P);
+        if (steps & STEP_POST_SETUP) d_post_setup(sh, s, a.ov, lvl_b, a.P);
         if (steps & STEP_POST_DECIDE) d_post_decide(sh, s, a.ov, a.carrier_freq, lvl_a);
         if (steps & STEP_TOTALS) d_totals(sh, s, a.table, a.pos_info_out, a.r_len_out);
-        if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts);
+        if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts, a.P);
     }
     __syncthreads();
     TAIL_STAMP(11);

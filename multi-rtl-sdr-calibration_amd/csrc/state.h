@@ -91,6 +91,12 @@ struct alignas(16) StreamState {
     int stage_status[4];     // per reference function: fine, sch, post, coarse
 };
 
+// the tunable thresholds of gsmcal_params as the kernels see them (by value inside StepArgs / CoarseArgs)
+struct DevParams {
+    double coarse_th, fine_max_ppm, fine_gate_snr, sch_max_ppm, scan_spacing, scan_spacing_idle, scan_tol;
+    int min_hits, post_min_bcch, scan_min_hits, pad;
+};
+
 struct PeakOut {  // partial result of k_slide_dft for one (window, bin-block)
     double p;     // best |X|^2
     int tie;      // tie-break key: shift index m (fine search) or fftshift-ed bin index (spectrum)

@@ -597,3 +597,52 @@ def test_inter_dongle_phase_difference_from_gathered_pos_info(g, setup):
         if tried == 2:
             break
     assert tried >= 1
+
+
+def test_fine_search_against_rocfft_spectra(g, setup):
+    """A third evaluation of FCCH_fine_correction.m:48-52, test-only: every one of the 1025 x 1184-point spectra of a hit by
+    rocFFT (torch.fft on the GPU), max over bins, first max over window starts -- against the first-round positions of
+    the HIP path's certificate / sweep / verify scheme (and the oracle's pocketfft).  No library FFT is on the product path."""
+    import torch
+    raw = np.stack([g.synth.make_stream(dongle=d)[0] for d in (0, 1, 4)])
+    g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    det = g.last_batch_details(len(raw))
+    r_all = g.frontend_batch(raw, setup["coef"], 1)                   # filter(coef,1,raw2iq(s)), every row (GPU, exact order)
+    dev = torch.device("cuda", 0)
+    for i in range(len(raw)):
+        nfine = det["counts"][i, 1]
+        assert nfine >= 5
+        r = torch.from_numpy(r_all[i]).to(dev)
+        for w in range(nfine):
+            cp = int(det["coarse_pos"][i, w])
+            sp = (cp - 64 - 1) * 8 + 1                               # :40,43 (1-based)
+            seg = r[sp - 1: sp - 1 + 1024 + 1184]
+            win = seg.unfold(0, 1184, 1)                             # (1025, 1184): window k = s(sp+k : sp+k+1183)
+            p = torch.fft.fft(win, dim=1).abs().square().amax(dim=1)
+            k = int(torch.argmax(p))                                 # torch.argmax: first maximum is not guaranteed ...
+            k = int((p == p[k]).nonzero()[0])                        # ... so take the first index holding it
+            assert det["fine_first"][i, w] == sp + k, f"stream {i} hit {w}: rocFFT says {sp + k}, HIP path {det['fine_first'][i, w]}"
+
+
+def test_params_pod_changes_decisions_and_rejects_geometry(g, setup):
+    """gsmcal_params: the thresholds the reference hard-codes.  An impossible SNR gate turns every calibrated stream into
+    the :192-196 sentinel; a relaxed scanner rule accepts two-hit captures; geometry fields are refused."""
+    raw = np.stack([g.synth.make_stream(dongle=d)[0] for d in (0, 3)])
+    c2 = g.Context(0)
+    try:
+        ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=c2)
+        assert np.any(ref["table"][:, 9] == 0)
+        c2.set_params(fine_gate_snr_db=200.0)
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=c2)
+        for i in range(2):
+            if ref["table"][i, 9] == 0:
+                assert out["table"][i, 9] == 6 and out["table"][i, 6] == 1          # GSMCAL_S_FINE_LOW_SNR, FCCH_pos = -1
+                parity.assert_ppm(out["table"][i, 0], ref["table"][i, 0], "sampling ppm is set before the gate")
+        c2.set_params(fine_gate_snr_db=5.0)
+        back = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=c2)
+        assert np.array_equal(back["table"], ref["table"], equal_nan=True)
+        with pytest.raises(g.GsmcalError):
+            c2.set_params(fine_max_offset=32)
+        assert c2.get_params().fine_max_offset == 64
+    finally:
+        c2.close()
