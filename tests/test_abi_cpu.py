@@ -96,35 +96,6 @@ def test_mex_gateway_covers_every_reference_function():
         assert f"defined(GSMCAL_FN_{t})" in src
 
 
-def test_host_side_under_address_sanitizer(tmp_path):
-    """SURVEY 5 (race detection / sanitizers): the reference has none; here the HOST side of libgsmcal.so is built with
-    AddressSanitizer (device code uninstrumented: GPU ASan is not available on this pool) and the GPU-less entry points
-    and failure paths run under it."""
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    clang = "/opt/rocm/lib/llvm/bin/clang"
-    if not (os.path.exists(hipcc) and os.path.exists(clang)):
-        pytest.skip("ROCm toolchain not present")
-    lib = tmp_path / "libgsmcal_asan.so"
-    src = os.path.join(ROOT, "multi-rtl-sdr-calibration_amd", "csrc", "gsmcal.hip")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address",
-                        "-fno-gpu-sanitize", "-shared-libsan", src, "-o", str(lib), "-ldl"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    exe = tmp_path / "asan_driver"
-    r = subprocess.run([clang, "-fsanitize=address", "-shared-libsan", "-I" + os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "tests", "asan_driver.c"), "-o", str(exe), "-L" + str(tmp_path), "-lgsmcal_asan",
-                        "-Wl,-rpath," + str(tmp_path), "-lm"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", LD_LIBRARY_PATH=str(tmp_path) + ":" + os.path.dirname(rt))
-    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
-    import torch
-    if not torch.cuda.is_available():
-        assert r.returncode == 0, r.stdout + r.stderr
-    assert "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-3000:]
-
-
 def test_params_defaults_are_the_reference_literals(gsmcal_mod):
     p = gsmcal_mod._lib.Params()
     gsmcal_mod.load().gsmcal_params_default(p)
