@@ -1428,8 +1428,17 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
                         d_pos_info ? d_pos_info + (size_t)lo * 2 * MAXROWS : nullptr,
                         d_r_len ? d_r_len + lo : nullptr));                                 // :120, :123-124
         if (d_r_correct) {
-            const int tiles = (int)((n + TILE - 1) / TILE);
-            RET_IF(launch_gather(c, S, src, 4, TILE, true, tiles, (cplx*)d_r_correct + (size_t)lo * n, n, 0));
+            StreamTileArgs ta;
+            ta.raw = raw_i; ta.raw_stride = 2 * n; ta.coef = (const double*)c->coef.p; ta.ntaps = ntaps;
+            ta.dst = (cplx*)d_r_correct + (size_t)lo * n; ta.dst_stream_stride = n;
+            const size_t tlds = stream_tile_lds(ntaps);
+            if (tlds <= 64 * 1024) {
+                LAUNCH(c, k_stream_tile, dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
+                CHECK_LAUNCH(c);
+            } else {                                        // very long filters: the general tile gather
+                const int tiles = (int)((n + TILE - 1) / TILE);
+                RET_IF(launch_gather(c, S, src, 4, TILE, true, tiles, (cplx*)d_r_correct + (size_t)lo * n, n, 0));
+            }
         }
     }
     c->cf_lane = nullptr;

@@ -751,6 +751,243 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     return to_lds ? src : nullptr;   // after the last swap `src` is the buffer written last
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stream_tile: the corrected stream r_correct (gsm_sync_demod.m:118-120 hands it on to SCH_demod), one tile of
+// ST_TILE output samples per workgroup -- the 18 B/sample mode of the batch path.  Same arithmetic per sample as
+// gather_core at level 4 (raw -> raw2iq -> filter -> interp1 -> exp derotation -> interp1 -> exp derotation), organised
+// for throughput instead of generality:
+//   * three passes through LDS instead of five: FIR | lerp + derotation | lerp + derotation -> global;
+//   * the derotation exp(1i*k*c) (FCCH_fine_correction.m:165, carrier_correct_post_SCH.m:83) comes from a per-tile
+//     two-level rotator table, exp(1i*k*c) = S * A[(k-k0)>>5] * B[(k-k0)&31] with S = exp(1i*fl(k0*c)),
+//     A[j] = exp(1i*fl(32j*c)), B[m] = exp(1i*fl(m*c)) -- 66 accurate sincos per tile instead of two per sample.  The
+//     reference rounds k*c once; the three rounded pieces differ from that by < 2 ulp(k*c) ~ 3e-11 rad at k = 1e6,
+//     far inside the 2e-8 stream tolerance (the argument of the reference's own exp carries the same uncertainty
+//     from the estimated c).
+// Streams whose chain is not (lerp, mix, lerp|copy, mix) have no r_correct (r = -1) and are skipped.
+// grid (ceil(N/ST_TILE), S), block 256.
+// ------------------------------------------------------------------------------------------------
+#define ST_TILE 1016            /* level-4 samples per tile: with the <= 8 extra level-0 samples of the two lerps one FIR round of 256 x 4 */
+#define ST_THREADS 256
+#define ST_TPB 8                /* consecutive tiles per workgroup (state, taps and the A/B rotator tables are set up once) */
+struct StreamTileArgs {
+    const uint8_t* raw; long raw_stride;
+    const double* coef; int ntaps;
+    cplx* dst; long dst_stream_stride;
+};
+__host__ __device__ inline size_t stream_tile_lds(int ntaps) {
+    const size_t span = 1024 + 8 + ntaps + 24;                    // level-0 samples a tile can need + taps + alignment slack
+    const size_t xs_n = span + span / 4 + 16;                     // padded complex input
+    const size_t buf = 1024 + 16;
+    // buf0 | region1 = max(xs, buf1) | coef | raw ushorts | rotator tables 2 x (2 + 34 + 32)
+    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * 8 + ((span + 7) & ~(size_t)7) * 2 +
+           2 * 68 * sizeof(cplx);
+}
+
+// T[0], T[1] = S of the current / next tile, T[2..35] = A[0..33], T[36..67] = B[0..31]
+__device__ __forceinline__ cplx st_rot(const cplx* T, int sidx, int m) {     // exp(1i*(k0+m)*c), 0 <= m < 34*32
+    const cplx sa = cmul(T[sidx], T[2 + (m >> 5)]);
+    return cmul(sa, T[36 + (m & 31)]);
+}
+
+struct StRange { long lo0, hi0, lo2, hi2, lo3; int L4, cnt0, cnt2; };
+__device__ __forceinline__ StRange st_range(long tile, long nq, long n0, long n2, double f1, double f3) {
+    StRange r;
+    r.lo3 = tile * ST_TILE;
+    r.L4 = (int)(nq - r.lo3 < ST_TILE ? nq - r.lo3 : ST_TILE);
+    const long hi3 = r.lo3 + r.L4 - 1;
+    r.lo2 = (long)floor((double)r.lo3 * f3);
+    r.hi2 = (long)floor((double)hi3 * f3) + 1;
+    if (r.hi2 > n2 - 1) r.hi2 = n2 - 1;
+    r.lo0 = (long)floor((double)r.lo2 * f1);
+    r.hi0 = (long)floor((double)r.hi2 * f1) + 1;
+    if (r.hi0 > n0 - 1) r.hi0 = n0 - 1;
+    r.cnt0 = (int)(r.hi0 - r.lo0 + 1);
+    r.cnt2 = (int)(r.hi2 - r.lo2 + 1);
+    return r;
+}
+
+__global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* __restrict__ sts, StreamTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const StreamState* st = sts + s;
+    // ---- chain (all fields fetched up front) ----
+    const long n0 = st->n0;
+    const double mr = st->mean_re, mi = st->mean_im;
+    int ty[NLEVELS]; double pa[NLEVELS]; long ln[NLEVELS];
+    ty[0] = OP_NONE; pa[0] = 0.0; ln[0] = n0;
+#pragma unroll
+    for (int j = 1; j < NLEVELS; ++j) { ty[j] = st->op[j].type; pa[j] = st->op[j].param; ln[j] = st->op[j].n; }
+    if (ty[1] != OP_LERP || ty[2] != OP_MIX || (ty[3] != OP_LERP && ty[3] != OP_COPY) || ty[4] != OP_MIX) return;
+    const double f1 = pa[1], c2 = pa[2], f3 = ty[3] == OP_COPY ? 1.0 : pa[3], c4 = pa[4];
+    const long nq = ln[4];
+    const long ntile = (nq + ST_TILE - 1) / ST_TILE;
+    long tile = (long)blockIdx.x * ST_TPB;
+    if (tile >= ntile) return;
+    const long tile_end = tile + ST_TPB < ntile ? tile + ST_TPB : ntile;
+    // ---- LDS carve ----
+    const int ntp = a.ntaps;
+    const size_t span_max = 1024 + 8 + ntp + 24;
+    const size_t xs_n = span_max + span_max / 4 + 16, bufn = 1024 + 16;
+    cplx* buf0 = (cplx*)smem;                                   // level 0 (FIR output)
+    cplx* buf1 = buf0 + bufn;                                   // level 2 (after lerp + derotation); aliases xs
+    cplx* xs = buf1;
+    double* c_s = (double*)(buf1 + (xs_n > bufn ? xs_n : bufn));
+    unsigned short* r_s = (unsigned short*)(c_s + ((ntp + 1) & ~1));
+    cplx* T2 = (cplx*)(r_s + ((span_max + 7) & ~(size_t)7));
+    cplx* T4 = T2 + 68;
+    const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
+    const long ao = (long)(((uintptr_t)base >> 1) & 7);         // samples past a 16-byte boundary at g = 0
+    // ---- once per workgroup: taps, the stream's A/B rotator tables, the first tile's S and raw bytes ----
+    for (int i = tid; i < ntp; i += ST_THREADS) c_s[i] = a.coef[i];
+    StRange rg = st_range(tile, nq, n0, ln[2], f1, f3);
+    if (tid >= 64 && tid < 64 + 2 * 66) {                       // A[j] = exp(1i*fl(32j*c)), B[m] = exp(1i*fl(m*c)) for both derotations
+        const int i = (tid - 64) % 66, which = (tid - 64) / 66;
+        const double c = which ? c4 : c2;
+        double sn, cs;
+        sincos_large(i < 34 ? (double)(32 * i) * c : (double)(i - 34) * c, &sn, &cs);
+        (which ? T4 : T2)[2 + i] = make_double2(cs, sn);
+    } else if (tid < 2) {                                       // S = exp(1i*fl(k0*c)) of the first tile
+        double sn, cs;
+        sincos_large(tid ? (double)rg.lo3 * c4 : (double)rg.lo2 * c2, &sn, &cs);
+        (tid ? T4 : T2)[0] = make_double2(cs, sn);
+    }
+    long first = rg.lo0 - (ntp - 1);
+    long first_al = stage_raw(r_s, base, n0, first, rg.cnt0 + ntp - 1, tid, ST_THREADS);
+    __syncthreads();
+    int sidx = 0;
+    for (; tile < tile_end; ++tile) {
+        const int cnt0 = rg.cnt0, cnt2 = rg.cnt2, L4 = rg.L4;
+        const long lo0 = rg.lo0, lo2 = rg.lo2, lo3 = rg.lo3;
+        {   // raw2iq.m:6-8 on the staged span
+            const int span = cnt0 + ntp - 1, off = (int)(first - first_al);
+            for (int i = tid; i < span + 8; i += ST_THREADS) {
+                const long g = first + i;
+                cplx v = make_double2(0.0, 0.0);
+                if (i < span && g >= 0 && g < n0) {
+                    const unsigned short q = r_s[off + i];
+                    v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
+                }
+                xs[xs_pad(i)] = v;
+            }
+        }
+        __syncthreads();                                        // xs complete; r_s is free again
+        // ---- the next tile's raw bytes (one 16-byte chunk per lane) and S: issued now, they land under the FIR ----
+        StRange nx = rg;
+        uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+        long nfirst = 0, nfirst_al = 0;
+        int nchunk = 0;
+        const bool more = tile + 1 < tile_end;
+        if (more) {
+            nx = st_range(tile + 1, nq, n0, ln[2], f1, f3);
+            nfirst = nx.lo0 - (ntp - 1);
+            long m = (nfirst + ao) % 8;
+            if (m < 0) m += 8;
+            nfirst_al = nfirst - m;
+            nchunk = (int)((nfirst + nx.cnt0 + ntp - 1 - nfirst_al + 7) >> 3);
+            if (tid < nchunk) {
+                const long g0 = nfirst_al + 8L * tid;
+                if (g0 >= 0 && g0 + 8 <= n0) pre = *(const uint4*)(base + g0);
+                else {
+                    unsigned short q[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = (g0 + i >= 0 && g0 + i < n0) ? base[g0 + i] : (unsigned short)0;
+                    pre.x = q[0] | ((unsigned)q[1] << 16); pre.y = q[2] | ((unsigned)q[3] << 16);
+                    pre.z = q[4] | ((unsigned)q[5] << 16); pre.w = q[6] | ((unsigned)q[7] << 16);
+                }
+            }
+        }
+        // ---- pass 1: filter(coef,1,.) -> buf0, four consecutive outputs per lane, oldest tap first (gather_core's loop).
+        // (Two outputs per lane with twice the threads ran 40 % slower: the LDS reads per FMA double.) ----
+        for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * ST_THREADS) {
+            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
+            cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
+#define ST_FIR_TAP(C, A, B, D, E)                                   \
+            ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);         \
+            ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
+            ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
+            ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
+            int t = 0;
+            for (; t + 4 <= ntp; t += 4) {
+                const cplx* nxs = xs + xs_pad(i0 + t + 4);
+                const cplx n0s = nxs[0], n1s = nxs[1], n2s = nxs[2], n3s = nxs[3];
+                const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2_ = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];
+                ST_FIR_TAP(c0, w0, w1, w2, w3)
+                ST_FIR_TAP(c1, w1, w2, w3, n0s)
+                ST_FIR_TAP(c2_, w2, w3, n0s, n1s)
+                ST_FIR_TAP(c3, w3, n0s, n1s, n2s)
+                w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
+            }
+            int p = i0 + t + 3;
+            for (; t < ntp; ++t) {
+                const double c = c_s[ntp - 1 - t];
+                ST_FIR_TAP(c, w0, w1, w2, w3)
+                w0 = w1; w1 = w2; w2 = w3;
+                ++p;
+                w3 = xs[xs_pad(p)];
+            }
+#undef ST_FIR_TAP
+            buf0[i0] = make_double2(ar0, ai0);
+            if (i0 + 1 < cnt0) buf0[i0 + 1] = make_double2(ar1, ai1);
+            if (i0 + 2 < cnt0) buf0[i0 + 2] = make_double2(ar2, ai2);
+            if (i0 + 3 < cnt0) buf0[i0 + 3] = make_double2(ar3, ai3);
+        }
+        if (more) {                                             // the prefetched bytes go to LDS; the next tile's S to the other slot
+            if (tid < nchunk) *(uint4*)(r_s + 8 * tid) = pre;
+            for (int cch = tid + ST_THREADS; cch < nchunk; cch += ST_THREADS) {   // (spans beyond 2048 samples: long filters)
+                const long g0 = nfirst_al + 8L * cch;
+                unsigned short q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = (g0 + i >= 0 && g0 + i < n0) ? base[g0 + i] : (unsigned short)0;
+                uint4 v;
+                v.x = q[0] | ((unsigned)q[1] << 16); v.y = q[2] | ((unsigned)q[3] << 16);
+                v.z = q[4] | ((unsigned)q[5] << 16); v.w = q[6] | ((unsigned)q[7] << 16);
+                *(uint4*)(r_s + 8 * cch) = v;
+            }
+            if (tid >= ST_THREADS - 2) {
+                double sn, cs;
+                sincos_large(tid == ST_THREADS - 1 ? (double)nx.lo3 * c4 : (double)nx.lo2 * c2, &sn, &cs);
+                (tid == ST_THREADS - 1 ? T4 : T2)[sidx ^ 1] = make_double2(cs, sn);
+            }
+        }
+        __syncthreads();                                        // (xs is dead: buf1 may be written)
+        // ---- pass 2: level 1 = interp1 (FCCH_fine_correction.m:123-125), level 2 = .* exp(1i*k*c2) (:165) -> buf1 ----
+        {
+            const double dlo2 = (double)lo2, dlo0 = (double)lo0;    // (indices < 2^53: the double sums and differences below are exact)
+            const int last0 = cnt0 - 1;
+            for (int i = tid; i < cnt2; i += ST_THREADS) {
+                const double xq = (dlo2 + (double)i) * f1;      // interp_seq = (0:max_len-1)'.*(1+e)
+                const double j0f = floor(xq);
+                const int j0 = (int)(j0f - dlo0);
+                const int j1 = j0 + 1 > last0 ? last0 : j0 + 1; // beyond the last sample the weight is 0
+                const double t = xq - j0f;
+                const cplx v0 = buf0[j0], v1 = buf0[j1];
+                const cplx v = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
+                buf1[i] = cmul(v, st_rot(T2, sidx, i));
+            }
+        }
+        __syncthreads();
+        // ---- pass 3: level 3 = interp1 (SCH_corr_rate_correction.m:126-127), level 4 = .* exp(1i*k*c4)
+        // (carrier_correct_post_SCH.m:83) -> global, one coalesced 16-byte store per lane ----
+        cplx* dst = a.dst + (size_t)s * a.dst_stream_stride + lo3;
+        {
+            const double dlo3 = (double)lo3, dlo2 = (double)lo2;
+            const int last2 = cnt2 - 1;
+            for (int i = tid; i < L4; i += ST_THREADS) {
+                const double xq = (dlo3 + (double)i) * f3;
+                const double j0f = floor(xq);
+                const int j0 = (int)(j0f - dlo2);
+                const int j1 = j0 + 1 > last2 ? last2 : j0 + 1;
+                const double t = xq - j0f;
+                const cplx v0 = buf1[j0], v1 = buf1[j1];
+                const cplx v = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
+                dst[i] = cmul(v, st_rot(T4, sidx, i));
+            }
+        }
+        __syncthreads();                                        // buf1 (= xs) and the tables' S slot may be rewritten
+        rg = nx; first = nfirst; first_al = nfirst_al; sidx ^= 1;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gather(const StreamState* __restrict__ sts, GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);

@@ -1,4 +1,4 @@
-/* Host-side AddressSanitizer driver (tests/test_abi_cpu.py builds libgsmcal.so with -fsanitize=address -fno-gpu-sanitize
+/* Host-side AddressSanitizer driver (tests/test_asan_cpu.py builds libgsmcal.so with -fsanitize=address -fno-gpu-sanitize
  * and runs this): the entry points that need no GPU, and the failure paths a GPU-less machine takes. */
 #include <math.h>
 #include <stdio.h>
