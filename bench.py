@@ -164,34 +164,27 @@ def main():
 
     # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
     # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written, and the only wait is
-    # before a buffer is written again two steps later.  Uneven shards (strong scaling) are padded to the largest.
-    gath = [torch.zeros((world * Dmax, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
-    send = [torch.full((Dmax, gsmcal.TABLE_COLS), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
-    host_gath = [torch.zeros((world * Dmax, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
-    works = [None, None]
+    # before a buffer is written again two steps later (gsmcal.dist.TableGatherer; uneven shards are padded).
+    tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev) if use_dist else None
+    host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
 
     def step():
         b = (nstep[0] & 1) if use_dist else 0
         nstep[0] += 1
-        if use_dist and works[b] is not None:
-            works[b].wait()
+        if use_dist:
+            tg.wait(b)
         cal.launch(b)
         if use_dist:
-            src = cal.table_t[b]
-            if D != Dmax:
-                send[b][:D].copy_(src)
-                src = send[b]
-            works[b] = dist.all_gather_into_tensor(gath[b], src, async_op=True)    # one RCCL all-gather of the ppm table
+            tg.post(b, cal.table_t[b])                               # one RCCL all-gather of the ppm table
         else:
             cal.to_host(b)
 
     def fence():
-        for b in range(2):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
-                host_gath[b].copy_(gath[b], non_blocking=True)      # gathered table to the host (every rank)
+        if use_dist:
+            for b in range(2):
+                if tg.work[b] is not None:
+                    host_gath[b].copy_(tg.rows(b), non_blocking=True)   # gathered table to the host (every rank)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -216,9 +209,8 @@ def main():
         parity.compare_stream(oracle.calibrate_stream(distinct[i], coef, ts, fc), table[i], det, i, _pos_info(pos_host, table, i))
         n_rank_checked += 1
     if use_dist:
-        g = host_gath[last].numpy()
-        off = rank * Dmax
-        assert np.array_equal(g[off:off + D], table, equal_nan=True), "all-gathered table differs from this rank's rows"
+        assert np.array_equal(tg.own_rows(last).cpu().numpy(), table, equal_nan=True), "all-gathered table differs from this rank's rows"
+        assert host_gath[last].shape[0] == sum(sizes)
 
     n_ok = int(np.sum(table[:, 9] == 0))
     total_samples = sum(sizes) * N * args.steps

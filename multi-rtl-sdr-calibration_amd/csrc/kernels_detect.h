@@ -750,16 +750,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
 // ---- 37 x N2 Cooley-Tukey building blocks (N2 = 4*ov; 32 for the reference's 8x oversampling) ----
 // tables in LDS: w37[m] = exp(-2 pi i m/37), wN2[m] = exp(-2 pi i m/N2); the inter-stage twiddle
 // exp(-2 pi i n2 k1 / nfft) comes from the global table tw_g (one read per output).
-__device__ __forceinline__ void fft37_tables(cplx* w37, cplx* wN2, int N2, int tid) {
-    if (tid < 37) {
-        double sn, cs;
-        sincospi(-2.0 * (double)tid / 37.0, &sn, &cs);
-        w37[tid] = make_double2(cs, sn);
-    } else if (tid >= 64 && tid < 64 + N2) {
-        double sn, cs;
-        sincospi(-2.0 * (double)(tid - 64) / (double)N2, &sn, &cs);
-        wN2[tid - 64] = make_double2(cs, sn);
-    }
+// (taken from the global table: W_37^m = W_nfft^(N2 m) and W_N2^m = W_nfft^(37 m) are the very same correctly rounded
+// values sincospi would give, without 69 lanes of fp64 sincospi at the head of every workgroup)
+__device__ __forceinline__ void fft37_tables(cplx* w37, cplx* wN2, int N2, int tid, const cplx* __restrict__ tw_g) {
+    if (tid < 37) w37[tid] = tw_g[N2 * tid];
+    else if (tid >= 64 && tid < 64 + N2) wN2[tid - 64] = tw_g[37 * (tid - 64)];
 }
 
 // step 1: B[k1][n2] = W_nfft^(n2*k1) * sum_n1 x[N2*n1+n2] * W_37^(n1*k1)
@@ -909,7 +904,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
     const int tid = threadIdx.x;
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     for (int i = tid; i < nfft; i += FFT_THREADS) xs[i] = x[i];
-    fft37_tables(w37, wN2, N2, tid);
+    fft37_tables(w37, wN2, N2, tid, tw_g);
     __syncthreads();
     fft37_step1_sym(xs, B, w37, tw_g, nfft, N2, ldb, tid, FFT_THREADS);
     __syncthreads();
@@ -1047,7 +1042,7 @@ __global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu
     const int nstep = nshift - 1;
     const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
     const int total = *n_items;
-    fft37_tables(w37, wN2, N2, tid);
+    fft37_tables(w37, wN2, N2, tid, tw_g);
     DEV_STAMP(KID_CHUNK, blockIdx.x, 0);
     for (int it = blockIdx.x; it < total; it += gridDim.x) {   // open (window, chunk) items, block-uniform
     const int item = items[it];

@@ -74,7 +74,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     __shared__ int sh_key;
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     BT_STAMP(0);
-    cplx* xs = gather_core<BT_THREADS>(sts, a, smem, w, s, true);   // nfft samples of the burst, in LDS
+    cplx* xs = gather_core<BT_THREADS, GATE ? KID_BT1 : KID_BT0>(sts, a, smem, w, s, true);   // nfft samples of the burst, in LDS
     if (!xs) return;                                                // block-uniform
     __syncthreads();
     BT_STAMP(1);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     cplx* w37 = (cplx*)(smem + gc.total);
     cplx* wN2 = w37 + 40;
     double* P = (double*)(wN2 + N2);
-    fft37_tables(w37, wN2, N2, tid);
+    fft37_tables(w37, wN2, N2, tid, tw_g);
     __syncthreads();
     // ---- spectrum argmax, first max in fftshift order (:149-150) ----
     // Fast exact route: the window is centred on the FCCH tone, so nearly all of its energy sits in a few bins

@@ -563,8 +563,9 @@ __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 struct GatherCarve {
     size_t bufn;          // elements per window buffer (0: none)
     size_t off_region1;   // buf1 / xs
-    size_t off_coef, off_raw, total;
+    size_t off_coef, off_raw, off_rot, total;
 };
+#define GC_ROT_A 72                     /* rotator table: S | A[0..GC_ROT_A) | B[0..32): windows of up to 32*GC_ROT_A samples */
 __host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind, int ntaps, bool to_lds) {
     GatherCarve g;
     g.bufn = (level >= 1 || to_lds) ? (size_t)len + 40 : 0;          // +40: room for B[37][N2+1] of the fused kernels
@@ -577,6 +578,11 @@ __host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind
     g.off_coef = g.off_region1 + r1 * 16;
     g.off_raw = g.off_coef + (size_t)((ntaps + 1) & ~1) * 8;
     g.total = (g.off_raw + ((span_max + 7) & ~(size_t)7) * 2 + 15) & ~(size_t)15;
+    // the rotator table of a derotation level lives where the raw bytes were (dead once level 0 exists); array sources
+    // have no raw region, so it is appended there
+    g.off_rot = g.off_raw;
+    const size_t rot_end = g.off_rot + (size_t)(1 + GC_ROT_A + 32) * 16;
+    if (level >= 2 && rot_end > g.total) g.total = (rot_end + 15) & ~(size_t)15;
     return g;
 }
 
@@ -585,9 +591,10 @@ __host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind
 // stays in LDS and its address is returned (nullptr if this block has no window).
 // The block's window index is `widx`, its stream `s`.  smem: the dynamic LDS base, carved as
 //   buf0 | buf1 (aliased with the padded complex input xs) | coef | raw ushorts     (GatherCarve).
-template <int NT>
+template <int NT, int KID = -1>
 __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts, const GatherArgs& a,
                                              unsigned char* smem, int widx, int s, bool to_lds) {
+#define GC_STAMP(i) do { if (KID >= 0) DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, i); } while (0)
     // LDS carve (GatherCarve, shared with the host and the fused kernels):
     //   buf0 | region1 = buf1 ALIASED WITH xs (padded complex input) | coef | raw ushorts
     // xs is dead once level 0 is in buf0, and buf1 is first written at level 1, so they share storage.
@@ -660,8 +667,10 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         const long first = lo0 - (ntp - 1);
         const int span = cnt0 + ntp - 1;
         for (int i = tid; i < ntp; i += NT) c_s[i] = a.coef[i];
+        GC_STAMP(9);
         const long first_al = stage_raw(r_s, base, n0, first, span, tid, NT);
         __syncthreads();
+        GC_STAMP(10);
         // raw2iq.m:6-8 on the staged span: (I - mean) + 1i (Q - mean); zero before the stream starts
         // (filter()'s zero initial state) and past its end
         const double mr = pre_mr, mi = pre_mi;
@@ -676,6 +685,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             xs[xs_pad(i)] = v;
         }
         __syncthreads();
+        GC_STAMP(11);
         // filter(coef,1,.) : y[i] = sum_k coef[k] x[i-k], accumulated oldest tap first (transposed
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
@@ -715,6 +725,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             if (i0 + 3 < cnt0) out0[i0 + 3] = make_double2(ar3, ai3);
         }
     }
+    GC_STAMP(12);
     // ---- levels 1..level ----
     cplx* src = buf0;
     cplx* other = buf1;
@@ -735,6 +746,22 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
                 const cplx v0 = src[i0 - plo], v1 = src[i1 - plo];
                 o[i] = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
             }
+        } else if (type == OP_MIX && cnt <= 32 * GC_ROT_A) {
+            // exp(1i*(0:len-1)'*comp_phase_rotate) from a two-level rotator table of the window:
+            // exp(1i*k*c) = S * A[(k-k0)>>5] * B[(k-k0)&31], S = exp(1i*fl(k0*c)), A[q] = exp(1i*fl(32q*c)), B[m] = exp(1i*fl(m*c))
+            // -- 1 + ceil(cnt/32) + 32 accurate sincos per window instead of one per sample.  The reference rounds k*c once;
+            // the three rounded pieces differ from that by < 2 ulp(k*c) ~ 3e-11 rad at k = 1e6 (see k_stream_tile).
+            cplx* T = (cplx*)(smem + gc.off_rot);
+            const int na = (cnt + 31) >> 5;
+            for (int i = threadIdx.x; i < 1 + na + 32; i += NT) {
+                const double arg = i == 0 ? (double)lo[j] * p : (i <= na ? (double)(32 * (i - 1)) * p : (double)(i - 1 - na) * p);
+                double sn, cs;
+                sincos_large(arg, &sn, &cs);
+                T[i == 0 ? 0 : (i <= na ? i : 1 + GC_ROT_A + (i - 1 - na))] = make_double2(cs, sn);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt; i += NT)
+                o[i] = cmul(src[i], cmul(cmul(T[0], T[1 + (i >> 5)]), T[1 + GC_ROT_A + (i & 31)]));
         } else if (type == OP_MIX) {
             for (int i = threadIdx.x; i < cnt; i += NT) {
                 const long k = lo[j] + i;
@@ -748,6 +775,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         cplx* tmp = src; src = other; other = tmp;
         (void)tmp;
     }
+    GC_STAMP(13);
+#undef GC_STAMP
     return to_lds ? src : nullptr;   // after the last swap `src` is the buffer written last
 }
 

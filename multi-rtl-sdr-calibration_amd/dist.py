@@ -44,6 +44,53 @@ def allgather_table(local_table, num_units: int, group=None):
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+class TableGatherer:
+    """The exchange step of bench.py: the all-gather of step i runs while step i+1 computes.  Two send / receive buffer
+    pairs alternate; `post(b, local)` pads this rank's rows to the largest shard and starts the (asynchronous)
+    collective on pair b, `wait(b)` completes it and `rows(b)` returns the table in global unit order.  Works on any
+    torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, sizes, cols, device, dtype=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.sizes = list(sizes)
+        self.world = len(self.sizes)
+        self.rank = dist.get_rank(group)
+        self.mx = max(self.sizes)
+        dtype = dtype or torch.float64
+        self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+
+    def post(self, b, local):
+        if local.shape[0] != self.sizes[self.rank]:
+            raise ValueError("local table does not match this rank's shard")
+        self.wait(b)
+        src = local
+        if local.shape[0] != self.mx:                      # uneven shards: pad to the largest (NaN rows are dropped by rows())
+            self.send[b][: local.shape[0]].copy_(local)
+            src = self.send[b]
+        self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], src.contiguous(), group=self.group, async_op=True)
+
+    def wait(self, b):
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+
+    def rows(self, b):
+        import torch
+        self.wait(b)
+        if all(s == self.mx for s in self.sizes):
+            return self.recv[b]
+        return torch.cat([self.recv[b][r * self.mx: r * self.mx + self.sizes[r]] for r in range(self.world)], dim=0)
+
+    def own_rows(self, b):
+        """this rank's rows inside the gathered buffer (for the self-check)"""
+        off = self.rank * self.mx
+        return self.recv[b][off: off + self.sizes[self.rank]]
+
+
 class NativeComm:
     """The same collective without PyTorch: gsmcal_allgather_table of the C ABI (RCCL, enqueued on the context's
     stream).  Bootstrap by a file every rank can see (rank 0 writes the 128-byte id) or by an id passed in."""

@@ -50,6 +50,54 @@ def test_allgather_table_world2(num_units):
         assert np.array_equal(res[r], want)
 
 
+def _gatherer_worker(rank, world, num_units, port, q):
+    sys.path.insert(0, ROOT)
+    import gsmcal
+    from gsmcal import dist as gd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = gd.shard_sizes(num_units, world)
+    lo, hi = gd.shard_range(num_units, world, rank)
+    tg = gd.TableGatherer(sizes, gsmcal.TABLE_COLS, torch.device("cpu"))
+    outs = []
+    for step in range(5):                                   # bench.py's loop: post step i, wait for it two steps later
+        b = step & 1
+        tg.wait(b)
+        local = torch.tensor(np.stack([_unit_row(u, gsmcal.TABLE_COLS) + 1000.0 * step for u in range(lo, hi)]))
+        tg.post(b, local)
+        if step >= 1:
+            outs.append(tg.rows(1 - b).clone().numpy())    # the previous step's table, complete by now
+            assert np.array_equal(tg.own_rows(1 - b).numpy(), outs[-1][lo:hi])
+    outs.append(tg.rows((5 - 1) & 1).clone().numpy())
+    q.put((rank, np.stack(outs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_units", [7, 64])
+def test_bench_exchange_step_under_gloo(num_units):
+    """The distributed half of bench.py (gsmcal.dist.TableGatherer: double-buffered, padded all-gather of the table) on
+    two gloo ranks, with the uneven 7-unit split (4 + 3 rows) and BASELINE config 4's 64 streams (strong scaling)."""
+    import gsmcal
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + num_units
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, num_units, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r].shape == (5, num_units, gsmcal.TABLE_COLS)
+        for step in range(5):
+            want = np.stack([_unit_row(u, gsmcal.TABLE_COLS) + 1000.0 * step for u in range(num_units)])
+            assert np.array_equal(res[r][step], want), f"rank {r} step {step}"
+
+
 def test_shard_ranges_cover_all_units():
     from gsmcal import dist as gd
     for u in (1, 7, 64, 102400):
