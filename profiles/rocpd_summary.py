@@ -3,8 +3,13 @@
 
     python profiles/rocpd_summary.py stats  <results.db> <out.csv> [skip_first_n_per_kernel]
     python profiles/rocpd_summary.py pmc    <fetch.db> <write.db> <out.json> <streams> <samples_per_stream>
+    python profiles/rocpd_summary.py sq     <sq.db> <out.csv>
 
 stats: per-kernel launch count, total / average / min / max duration (ns) -- the `--kernel-trace --stats` table.
+sq:    per-kernel means of every counter of an SQ pass (rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
+       SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY) plus derived columns: waves per launch, VALU
+       instructions per wave, share of wave-cycles with a VALU instruction in flight, share spent waiting (s_waitcnt / barrier),
+       LDS bank-conflict cycles per LDS instruction.  (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.)
 pmc:   FETCH_SIZE / WRITE_SIZE per launch (KiB as reported by rocprofv3), averaged over launches, plus the HBM
        bytes per launch after the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE of a wide coalesced
        streaming read reports half the bytes: doubled; WRITE_SIZE as reported).
@@ -51,6 +56,34 @@ def pmc_table(db, counter):
     return {k: sum(v.values()) / len(v) for k, v in per.items()}
 
 
+def sq(db, out):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    val_col = "value" if "value" in cols else "counter_value"
+    cn_col = "counter_name" if "counter_name" in cols else "pmc_name"
+    rows = cur.execute(f"select {name_col}, {cn_col}, {val_col}, dispatch_id from counters_collection").fetchall()
+    per = {}
+    for name, cn, val, did in rows:
+        per.setdefault(short(name), {}).setdefault(cn, {}).setdefault(did, 0.0)
+        per[short(name)][cn][did] += float(val)
+    counters = sorted({cn for v in per.values() for cn in v})
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Launches"] + counters + ["valu_insts_per_wave", "valu_active_share_of_wave_cycles",
+                                                      "wait_share_of_wave_cycles", "lds_conflict_cycles_per_lds_inst"])
+        for k in sorted(per, key=lambda k: -sum(per[k].get("SQ_BUSY_CYCLES", {0: 0.0}).values())):
+            m = {cn: (sum(per[k][cn].values()) / len(per[k][cn]) if cn in per[k] else 0.0) for cn in counters}
+            n = max(len(v) for v in per[k].values())
+            wv, wc = m.get("SQ_WAVES", 0.0), m.get("SQ_WAVE_CYCLES", 0.0)
+            li = m.get("SQ_INSTS_LDS", 0.0)
+            w.writerow([k, n] + [round(m[cn], 1) for cn in counters] +
+                       [round(m.get("SQ_INSTS_VALU", 0.0) / wv, 1) if wv else "",
+                        round(m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4) if wc else "",
+                        round(m.get("SQ_WAIT_ANY", 0.0) / wc, 4) if wc else "",
+                        round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / li, 3) if li else ""])
+
+
 def pmc(fetch_db, write_db, out, streams, samples):
     f, w = pmc_table(fetch_db, "FETCH_SIZE"), pmc_table(write_db, "WRITE_SIZE")
     raw, hbm = {}, {}
@@ -59,8 +92,8 @@ def pmc(fetch_db, write_db, out, streams, samples):
         hbm[k] = int(round((2.0 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
     with open(out, "w") as fh:
         json.dump({"streams_per_gpu": streams, "samples_per_stream": samples,
-                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 "
-                             "--warmup 2 --no-kernel-events`; KiB per launch averaged over launches; per MI355X_MICROARCH.md "
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (tools/profile_r02.sh); "
+                             " KiB per launch averaged over launches; per MI355X_MICROARCH.md "
                              "(HBM section) FETCH_SIZE of a wide coalesced stream is doubled on gfx950, WRITE_SIZE as reported",
                    "raw_kib_per_launch": raw, "hbm_bytes_per_launch": hbm}, fh, indent=1)
 
@@ -68,5 +101,7 @@ def pmc(fetch_db, write_db, out, streams, samples):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]))
