@@ -46,7 +46,7 @@ struct ProfRec {
 // A lane = one HIP stream + the per-stream-group scratch of the chain.  A batch is split over several
 // lanes so that one group's latency-bound stages (coarse scan, decisions, small FFTs) run underneath
 // another group's compute-bound fine search.  Lane 0 runs on the context's own stream.
-#define MAX_LANES 8
+#define MAX_LANES 16
 struct Lane {
     hipStream_t stream = nullptr;
     DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr;
@@ -624,7 +624,7 @@ int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
     // kernels in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms for 12,800 captures), so big scanner
     // batches are cut into pipeline stages instead: the front kernels run one after the other (chained by events) and
     // each stage's detector runs underneath the next stage's front kernel.
-    int nl = latency_bound ? c->n_lanes_cfg : (d >= 2048 ? 8 : 1);
+    int nl = latency_bound ? c->n_lanes_cfg : (d >= 8192 ? 16 : (d >= 2048 ? 8 : 1));
     if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;

@@ -1346,11 +1346,16 @@ __host__ inline int fc_threads(int nshift) {
     const int n = ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64;
     return n < 256 ? 256 : n;
 }
+// One element of padding after every 128: lane groups that work 64 shifts apart (the chunks of the slide phase) would
+// otherwise all hit the same LDS banks (8-way; the SQ counters showed 4 bank-conflict cycles per LDS instruction in this
+// kernel); this leaves them 2-way.  (Padding every 64 would clear them entirely but costs the third workgroup per CU: the
+// kernel sits 100 bytes under the 53 760-byte line.)
+#define FC_XP(p) ((p) + ((p) >> 7))
 __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
     const int nstep = nshift - 1, wlen = nstep + nfft, B = fc_gcd64(nfft);
     size_t r1 = (size_t)FC_NB * (wlen / B) * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
-    size_t r2 = (size_t)FC_NB * (B + 2 + nfft / B) * sizeof(cplx), e2 = (size_t)2 * (nstep + 2) * sizeof(float);
-    return (size_t)wlen * sizeof(cplx) + (r1 > e1 ? r1 : e1) + (r2 > e2 ? r2 : e2);
+    size_t r2 = (size_t)FC_NB * (B + 2 + nfft / B) * sizeof(cplx), e2 = (size_t)2 * (size_t)(FC_XP(nstep + 2) + 1) * sizeof(float) + 16 * sizeof(double);
+    return (size_t)FC_XP(wlen) * sizeof(cplx) + (r1 > e1 ? r1 : e1) + (r2 > e2 ? r2 : e2);
 }
 
 #define FC_PF 8   /* slide steps whose samples are fetched from LDS ahead of the arithmetic */
@@ -1365,24 +1370,25 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     const int nthr = blockDim.x;                          // >= 8 * nchunk, whole waves
     cplx* xs = (cplx*)smem;                               // window
     const size_t r1 = (size_t)FC_NB * nM * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
-    cplx* Sp = xs + wlen;                                 // S partials [j][m]
+    cplx* Sp = xs + FC_XP(wlen);                          // S partials [j][m]
     double* Et = (double*)Sp;                             // ... later E[t], t = 0..nstep
     unsigned char* reg2 = (unsigned char*)Sp + (r1 > e1 ? r1 : e1);
     const int ld1 = B + 2;                                // plane stride of tw1: spreads the 8 bins over the banks
     cplx* tw1 = (cplx*)reg2;                              // [j][b]  W^(k_j b)
     cplx* tw2 = tw1 + FC_NB * ld1;                        // [a][j]  W^(k_j B a)
     float* sumS = (float*)reg2;                           // ... later sum over S of P(t,k), t = 0..nstep
-    float* Cs = sumS + (nstep + 2);                       // ... and C(t) = sum_{q<t} |d_q|, the slack of the recurrence
+    float* Cs = sumS + FC_XP(nstep + 2);                  // ... and C(t) = sum_{q<t} |d_q|, the slack of the recurrence
+    double* sh_scan = (double*)(Cs + FC_XP(nstep + 2) + (FC_XP(nstep + 2) & 1));   // 2 x 8 scan partials behind them (same phases)
+    double* sh_scan2 = sh_scan + 8;
     __shared__ double red_p[8];
     __shared__ int red_t[8], red_k[8];
-    __shared__ double sh_scan[8], sh_scan2[8];
     __shared__ int sh_a, sh_b, sh_lo;
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 0);
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    for (int i = tid; i < wlen; i += nthr) xs[i] = x[i];
+    for (int i = tid; i < wlen; i += nthr) xs[FC_XP(i)] = x[i];
     if (tid == 0) { sh_a = 0; sh_b = nstep; }
     __syncthreads();
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 1);
@@ -1397,7 +1403,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         double* pw = (double*)(Sp + 296);
         for (int m = tid; m < 148; m += nthr) {
             double sr = 0.0, si = 0.0;
-            for (int i = 0; i < D; ++i) { const cplx v = xs[n0 + D * m + i]; sr += v.x; si += v.y; }
+            for (int i = 0; i < D; ++i) { const cplx v = xs[FC_XP(n0 + D * m + i)]; sr += v.x; si += v.y; }
             yd[m] = make_double2(sr, si);
             t148[m] = tw_g[D * m];
         }
@@ -1473,13 +1479,13 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     // ---- level 1: S_k(m) for all nM blocks of the window.  Lane (c, j) starts its block at sample c mod B so
     // that the groups of a wave read different LDS banks (the 8 lanes of a group share the sample: broadcast).
     for (int m = c; m < nM; m += nthr / FC_NB) {
-        const cplx* xb = xs + B * m;
+        const int xb0 = B * m;
         const cplx* tb = tw1 + j * ld1;
         double ar = 0.0, ai = 0.0;
         int b = c & (B - 1);
 #pragma unroll 4
         for (int i = 0; i < B; ++i) {
-            const cplx v = xb[b], t = tb[b];
+            const cplx v = xs[FC_XP(xb0 + b)], t = tb[b];
             ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
             ai = fma(v.x, t.y, fma(v.y, t.x, ai));
             b = (b + 1) & (B - 1);
@@ -1505,14 +1511,14 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     // ---- E(t): E(0) by a block reduction, then a block scan of g[q] = |x[q+nfft]|^2 - |x[q]|^2 ----
     {
         double e0 = 0.0;
-        for (int i = tid; i < nfft; i += nthr) e0 += xs[i].x * xs[i].x + xs[i].y * xs[i].y;
+        for (int i = tid; i < nfft; i += nthr) { const cplx v = xs[FC_XP(i)]; e0 += v.x * v.x + v.y * v.y; }
         for (int off = 32; off > 0; off >>= 1) e0 += __shfl_down(e0, off, 64);
         if (lane == 0) red_p[wave] = e0;
         const int per = (nstep + nthr - 1) / nthr;
         const int i0 = tid * per < nstep ? tid * per : nstep, i1 = i0 + per < nstep ? i0 + per : nstep;
         double loc = 0.0, locd = 0.0;
         for (int q = i0; q < i1; ++q) {
-            const cplx a1 = xs[q + nfft], b1 = xs[q];
+            const cplx a1 = xs[FC_XP(q + nfft)], b1 = xs[FC_XP(q)];
             loc += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
             const double dr = a1.x - b1.x, di = a1.y - b1.y;
             locd += sqrt(dr * dr + di * di);
@@ -1529,13 +1535,13 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         for (int i = 0; i < nwave; ++i) run += red_p[i];  // + E(0)
         for (int q = i0; q < i1; ++q) {
             Et[q] = run;
-            Cs[q] = (float)rund;
-            const cplx a1 = xs[q + nfft], b1 = xs[q];
+            Cs[FC_XP(q)] = (float)rund;
+            const cplx a1 = xs[FC_XP(q + nfft)], b1 = xs[FC_XP(q)];
             run += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
             const double dr = a1.x - b1.x, di = a1.y - b1.y;
             rund += sqrt(dr * dr + di * di);
         }
-        if (i1 == nstep && i0 < nstep) { Et[nstep] = run; Cs[nstep] = (float)rund; }
+        if (i1 == nstep && i0 < nstep) { Et[nstep] = run; Cs[FC_XP(nstep)] = (float)rund; }
     }
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 5);
     // ---- slides: lane (c, j) walks chunk c of bin k; the 8 lanes of a group share the shift ----
@@ -1548,15 +1554,14 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (c == 0) {                                     // the start window m = 0
             const double p = xr * xr + xi * xi;
             best = p; bt = 0;
-            sumS[0] = fc_group8_sum((float)p);
+            sumS[FC_XP(0)] = fc_group8_sum((float)p);
         }
-        const cplx* xa = xs + t0 + nfft;
-        const cplx* xb = xs + t0;
+        const int xa0 = t0 + nfft, xb0 = t0;
         for (int q0 = 0; q0 < FS_CHUNK; q0 += FC_PF) {
             double dr[FC_PF], di[FC_PF];
 #pragma unroll
             for (int u = 0; u < FC_PF; ++u) {             // all LDS reads of the group first: one wait, not FC_PF
-                const cplx a1 = xa[q0 + u], b1 = xb[q0 + u];
+                const cplx a1 = xs[FC_XP(xa0 + q0 + u)], b1 = xs[FC_XP(xb0 + q0 + u)];
                 dr[u] = a1.x - b1.x;
                 di[u] = a1.y - b1.y;
             }
@@ -1571,7 +1576,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                 ps[u] = fc_group8_sum((float)p);
             }
 #pragma unroll
-            for (int u = 0; u < FC_PF; ++u) sumS[t0 + q0 + u + 1] = ps[u];
+            for (int u = 0; u < FC_PF; ++u) sumS[FC_XP(t0 + q0 + u + 1)] = ps[u];
         }
     }
     int bk = k;
@@ -1605,13 +1610,13 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         double mf = INF, mb = INF;
         for (int t = u0; t < u1; ++t) {
             const double NE = (double)nfft * Et[t];
-            const float ss = sumS[t];
+            const float ss = sumS[FC_XP(t)];
             const double R = NE - (double)ss + 4e-6 * NE;
             double sv = ss <= 3.0e38f ? sqrt(R > 0.0 ? R : 0.0) * (1.0 + 1e-6) : INF;   // (an overflowed fp32 sum bounds nothing)
             if (!(sv >= 0.0)) sv = INF;                   // NaN input
             const float sf = (float)sv;
-            sumS[t] = sf;                                 // own range only: s(t) replaces the group sum
-            const double cv = (double)Cs[t];
+            sumS[FC_XP(t)] = sf;                          // own range only: s(t) replaces the group sum
+            const double cv = (double)Cs[FC_XP(t)];
             mf = fmin(mf, (double)sf - cv);
             mb = fmin(mb, (double)sf + cv);
         }
@@ -1630,16 +1635,16 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         __syncthreads();
         for (int i = 0; i < wave; ++i) ef = fmin(ef, sh_scan[i]);
         for (int i = wave + 1; i < nwave; ++i) eb = fmin(eb, sh_scan2[i]);
-        const double ctot = (double)Cs[nstep] * 1e-6;     // covers the fp32 rounding of the C(t) differences
+        const double ctot = (double)Cs[FC_XP(nstep)] * 1e-6;     // covers the fp32 rounding of the C(t) differences
         unsigned okm = 0;                                 // per <= 32 for every supported geometry
         for (int t = u0; t < u1; ++t) {
-            const double cv = (double)Cs[t];
-            ef = fmin(ef, (double)sumS[t] - cv);
+            const double cv = (double)Cs[FC_XP(t)];
+            ef = fmin(ef, (double)sumS[FC_XP(t)] - cv);
             if (cv + ef + ctot < sb) okm |= 1u << (t - u0);
         }
         for (int t = u1 - 1; t >= u0; --t) {
-            const double cv = (double)Cs[t];
-            eb = fmin(eb, (double)sumS[t] + cv);
+            const double cv = (double)Cs[FC_XP(t)];
+            eb = fmin(eb, (double)sumS[FC_XP(t)] + cv);
             const bool okc = ((okm >> (t - u0)) & 1u) || (eb - cv + ctot < sb);
             if (!okc) {
                 if (t <= bt) atomicMax(&sh_a, t + 1);     // uncertified prefix [0, a)
