@@ -14,13 +14,19 @@ os.environ.setdefault("OMP_NUM_THREADS", "1")
 FC = 957.4e6
 
 
+def _gen_one(args):
+    d, frames, kw = args
+    import gsmcal
+    return gsmcal.synth.make_stream(dongle=d, num_frames=frames, **kw)[0]
+
+
 def _oracle_one(args):
     d, frames, kw = args
     import gsmcal
     from oracle import gsmcal_oracle as o
     synth = gsmcal.synth
     raw, _ = synth.make_stream(dongle=d, num_frames=frames, **kw)
-    coef = o.fir1(46, 200e3 / synth.FS)
+    coef = synth.fir1(46, 200e3 / synth.FS)
     try:
         return d, o.calibrate_stream(raw, coef, synth.sch_training_sequence(), FC), None
     except o.MatlabIndexError as e:
@@ -50,13 +56,14 @@ def main():
             kw["carrier_ppm"] = float(rng.uniform(-60, 60))
         kws.append(kw)
     t0 = time.time()
-    raws = [synth.make_stream(dongle=first + i, num_frames=frames, **kws[i])[0] for i in range(n)]
-    raw = np.stack(raws)
+    workers = min(128, os.cpu_count() or 1)
+    jobs = [(first + i, frames, kws[i]) for i in range(n)]
+    with ProcessPoolExecutor(max_workers=workers) as ex:         # the pool is created before the GPU is touched
+        raw = np.stack(list(ex.map(_gen_one, jobs, chunksize=2)))
+        res = list(ex.map(_oracle_one, jobs, chunksize=2))
+    t1 = time.time()
     out = gsmcal.calibrate_batch(raw, coef, ts, FC)
     det = gsmcal.last_batch_details(n)
-    t1 = time.time()
-    with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(_oracle_one, [(first + i, frames, kws[i]) for i in range(n)]))
     bad = 0
     n_ok = 0
     for i, (d, orc, err) in enumerate(res):
@@ -71,7 +78,7 @@ def main():
         except AssertionError as e:
             bad += 1
             print(f"stream {d} {kws[i]}: MISMATCH {e}")
-    print(f"sweep: {n} streams, {n_ok} calibrated, {bad} mismatches; gpu+gen {t1 - t0:.1f}s oracle {time.time() - t1:.1f}s")
+    print(f"sweep: {n} streams from dongle {first}, {n_ok} calibrated, {bad} mismatches; gen+oracle {t1 - t0:.1f}s gpu {time.time() - t1:.1f}s")
     return 1 if bad else 0
 
 

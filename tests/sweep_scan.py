@@ -11,6 +11,12 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 
+def _gen(args):
+    a, kw = args
+    import gsmcal
+    return gsmcal.synth.make_stream(dongle=900, arfcn=a, num_frames=64, **kw)[0]
+
+
 def _one(args):
     a, kw = args
     import gsmcal
@@ -31,10 +37,11 @@ def main():
         if i % 4 == 1:
             kw["snr_db"] = float(rng.uniform(3, 15))
         kws.append(kw)
-    raw = np.stack([gsmcal.synth.make_stream(dongle=900, arfcn=first + i, num_frames=64, **kws[i])[0] for i in range(n)])
+    jobs = [(first + i, kws[i]) for i in range(n)]
+    with ProcessPoolExecutor(max_workers=min(128, os.cpu_count() or 1)) as ex:      # pool first, GPU afterwards
+        raw = np.stack(list(ex.map(_gen, jobs, chunksize=4)))
+        res = list(ex.map(_one, jobs, chunksize=4))
     out = gsmcal.fcch_scan_batch(raw, gsmcal.synth.fir1(30, 200e3 / gsmcal.synth.FS))
-    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(_one, [(first + i, kws[i]) for i in range(n)], chunksize=4))
     bad = 0
     for i, (snr, nh) in enumerate(res):
         if nh != out["num_hit"][i] or abs(snr - out["snr"][i]) > 1e-8:
