@@ -82,6 +82,7 @@ struct gsmcal_ctx {
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
+    bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     gsmcal_params params;           // thresholds (defaults = the reference's literals)
@@ -331,7 +332,25 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_FINE_SETUP>, dim3(S), dim3(64), 0, st, sa, lvl, 0);
-    RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
+    // raw sources at level 0: the certificate kernel builds the windows itself when a staging pass fits its free LDS
+    const int fc_thr = fc_threads(g.fine_nshift);
+    const size_t clds = (fc_lds_bytes(g.fine_nshift, g.nfft) + 15) & ~(size_t)15;
+    const bool cert_ok = c->prescreen && c->certify && fc_thr <= 512 && clds <= 159 * 1024 &&
+                         (g.fine_nshift - 1) % FS_CHUNK == 0 && g.nfft % 148 == 0 && g.nfft >= 2 * FC_NB;
+    FusedGather fg;
+    memset(&fg, 0, sizeof(fg));
+    if (cert_ok && src.kind == SRC_RAW && lvl == 0 && c->fuse_fine_gather) {
+        const size_t avail = clds - (size_t)FC_XP(g.fine_wlen) * sizeof(cplx) - 16;
+        for (int np = 2; np <= 8; ++np) {
+            const int per = ((g.fine_wlen + np - 1) / np + 3) & ~3;
+            if ((per + src.ntaps + 14) / 8 + 1 <= fc_thr && fc_stage_bytes(per, src.ntaps) <= avail) {
+                fg.raw = src.raw; fg.raw_stride = src.raw_stride; fg.coef = src.coef; fg.win_out = win;
+                fg.ntaps = src.ntaps; fg.per = per;
+                break;
+            }
+        }
+    }
+    if (!fg.raw) RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     StepArgs sa_fine = sa;
     if (c->prescreen) {
         // certificate (exact, tone bins) -> packed-fp32 sweep of the chunks it left open -> exact fp64 on what survives
@@ -348,13 +367,10 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         int* n_open = (int*)c->cur->openlist.p;
         int* open_items = n_open + 4;
         const FineCert* certp = nullptr;
-        const int fc_thr = fc_threads(g.fine_nshift);
-        const size_t clds = (fc_lds_bytes(g.fine_nshift, g.nfft) + 15) & ~(size_t)15;
-        if (c->certify && fc_thr <= 512 && clds <= 159 * 1024 && (g.fine_nshift - 1) % FS_CHUNK == 0 &&
-            g.nfft % 148 == 0 && g.nfft >= 2 * FC_NB) {
+        if (cert_ok) {
             RET_IF(ensure(c, c->cur->cert, (size_t)S * H * sizeof(FineCert)));
             LAUNCH(c, k_fine_cert, dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open);
+                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open, fg);
             certp = (const FineCert*)c->cur->cert.p;
         } else {
             LAUNCH(c, k_fine_openall, dim3(H, S), dim3(64), 0, (const StreamState*)st, nchunk, H, open_items, n_open);
@@ -808,6 +824,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (lm && atoi(lm) >= 1) c->lane_min = atoi(lm);
     const char* ce = getenv("GSMCAL_CERT");
     if (ce) c->certify = atoi(ce) != 0;
+    const char* fge = getenv("GSMCAL_FUSE_GATHER");
+    if (fge) c->fuse_fine_gather = atoi(fge) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");

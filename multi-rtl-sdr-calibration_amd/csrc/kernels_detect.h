@@ -1351,6 +1351,18 @@ __host__ inline int fc_threads(int nshift) {
 // kernel); this leaves them 2-way.  (Padding every 64 would clear them entirely but costs the third workgroup per CU: the
 // kernel sits 100 bytes under the 53 760-byte line.)
 #define FC_XP(p) ((p) + ((p) >> 7))
+// k_fine_cert building its window from the raw bytes itself (raw == nullptr: read it from `win`)
+struct FusedGather {
+    const uint8_t* raw; long raw_stride;
+    const double* coef;
+    cplx* win_out;
+    int ntaps, per;           // per: outputs per staging pass (multiple of 4)
+};
+// staging bytes of one pass: padded complex input | coefficients
+__host__ inline size_t fc_stage_bytes(int per, int ntaps) {
+    const int span8 = per + ntaps + 8;
+    return (size_t)(span8 + span8 / 4 + 1) * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * sizeof(double);
+}
 __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
     const int nstep = nshift - 1, wlen = nstep + nfft, B = fc_gcd64(nfft);
     size_t r1 = (size_t)FC_NB * (wlen / B) * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
@@ -1363,7 +1375,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                                                    const cplx* __restrict__ win, long win_stream_stride,
                                                    long win_stride, int nshift, int nfft,
                                                    const cplx* __restrict__ tw_g, FineCert* __restrict__ cert, int H,
-                                                   int* __restrict__ items, int* __restrict__ n_items) {
+                                                   int* __restrict__ items, int* __restrict__ n_items, FusedGather fg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nstep = nshift - 1, wlen = nstep + nfft;
     const int B = fc_gcd64(nfft), nA = nfft / B, nM = wlen / B, nchunk = nstep / FS_CHUNK;
@@ -1387,10 +1399,114 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-    for (int i = tid; i < wlen; i += nthr) xs[FC_XP(i)] = x[i];
-    if (tid == 0) { sh_a = 0; sh_b = nstep; }
-    __syncthreads();
+    if (fg.raw) {
+        // The window straight from the raw bytes (raw2iq.m:6-8 + filter(coef,1,.), gather_core's level 0 with the same
+        // order of operations), in passes of fg.per outputs staged through regions 1/2 (free until the tone estimate):
+        // the window never makes the trip through HBM before the first use, and the k_gather launch in front of this
+        // kernel is gone.  It is still written out for k_fine_chunk / k_fine_verify.
+        const StreamState* st = sts + s;
+        const long n0 = st->n0, ws = st->win_start[w];
+        const double mr = st->mean_re, mi = st->mean_im;
+        const int ntp = fg.ntaps, per = fg.per;
+        cplx* xq = (cplx*)Sp;
+        double* c_s = (double*)(xq + xs_pad(per + ntp + 8) + 1);
+        const unsigned short* base = (const unsigned short*)(fg.raw + (size_t)s * fg.raw_stride);
+        cplx* wout = fg.win_out + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+        for (int i = tid; i < ntp; i += nthr) c_s[i] = fg.coef[i];
+        // raw chunk `tid` of a pass (8 samples, 16-byte aligned), fetched one pass ahead so the loads overlap the FIR of
+        // the previous one; samples outside the stream read as 0 and are zeroed again after the mean is subtracted
+        const long ao = (long)(((uintptr_t)base >> 1) & 7);
+        auto raw_chunk = [&](long first, int span, long& first_al) -> uint4 {
+            long m = (first + ao) % 8;
+            if (m < 0) m += 8;
+            first_al = first - m;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const long g0 = first_al + 8L * tid;
+            if (g0 < first + span) {
+                if (g0 >= 0 && g0 + 8 <= n0) {
+                    v = *(const uint4*)(base + g0);
+                } else {
+                    unsigned short t[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[i] = (g0 + i >= 0 && g0 + i < n0) ? base[g0 + i] : (unsigned short)0;
+                    v.x = t[0] | ((unsigned)t[1] << 16); v.y = t[2] | ((unsigned)t[3] << 16);
+                    v.z = t[4] | ((unsigned)t[5] << 16); v.w = t[6] | ((unsigned)t[7] << 16);
+                }
+            }
+            return v;
+        };
+        long first_al;
+        uint4 pre = raw_chunk(ws - (ntp - 1), (per < wlen ? per : wlen) + ntp - 1, first_al);
+        for (int o0 = 0; o0 < wlen; o0 += per) {
+            const int cnt = wlen - o0 < per ? wlen - o0 : per;
+            const long first = ws + o0 - (ntp - 1);
+            const int span = cnt + ntp - 1;
+            {   // raw2iq.m:6-8 from the registers: staged sample i = 8*tid + u - (first - first_al); entries span .. span+7 are 0
+                const int i_base = 8 * tid - (int)(first - first_al);
+                const unsigned wv[4] = {pre.x, pre.y, pre.z, pre.w};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i_base + u;
+                    const long g = first + i;
+                    const unsigned q = (wv[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+                    cplx v = make_double2(0.0, 0.0);
+                    if (i < span && g >= 0 && g < n0) v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
+                    if (i >= 0 && i < span + 8) xq[xs_pad(i)] = v;
+                }
+            }
+            __syncthreads();
+            if (o0 == 0) DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 8);
+            if (o0 + per < wlen) {
+                const int ncnt = wlen - (o0 + per) < per ? wlen - (o0 + per) : per;
+                pre = raw_chunk(first + per, ncnt + ntp - 1, first_al);
+            }
+            for (int i0 = 4 * tid; i0 < cnt; i0 += 4 * nthr) {
+                double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
+                cplx w0 = xq[xs_pad(i0)], w1 = xq[xs_pad(i0 + 1)], w2 = xq[xs_pad(i0 + 2)], w3 = xq[xs_pad(i0 + 3)];
+#define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
+                ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);         \
+                ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
+                ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
+                ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
+                int t = 0;
+                for (; t + 4 <= ntp; t += 4) {        // gather_core's loop: every accumulator takes its taps oldest first
+                    const cplx* nx = xq + xs_pad(i0 + t + 4);
+                    const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
+                    const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];
+                    GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
+                    GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
+                    GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
+                    GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
+                    w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
+                }
+                int p = i0 + t + 3;
+                for (; t < ntp; ++t) {
+                    const double c = c_s[ntp - 1 - t];
+                    GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
+                    w0 = w1; w1 = w2; w2 = w3;
+                    ++p;
+                    w3 = xq[xs_pad(p)];
+                }
+#undef GSMCAL_FIR_TAP
+                const cplx y0 = make_double2(ar0, ai0), y1 = make_double2(ar1, ai1), y2 = make_double2(ar2, ai2),
+                           y3 = make_double2(ar3, ai3);
+                const int o = o0 + i0;
+                xs[FC_XP(o)] = y0; wout[o] = y0;
+                if (i0 + 1 < cnt) { xs[FC_XP(o + 1)] = y1; wout[o + 1] = y1; }
+                if (i0 + 2 < cnt) { xs[FC_XP(o + 2)] = y2; wout[o + 2] = y2; }
+                if (i0 + 3 < cnt) { xs[FC_XP(o + 3)] = y3; wout[o + 3] = y3; }
+            }
+            __syncthreads();
+            DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 9 + (o0 > 0) + (o0 > per));
+        }
+        if (tid == 0) { sh_a = 0; sh_b = nstep; }
+        __syncthreads();
+    } else {
+        const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+        for (int i = tid; i < wlen; i += nthr) xs[FC_XP(i)] = x[i];
+        if (tid == 0) { sh_a = 0; sh_b = nstep; }
+        __syncthreads();
+    }
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 1);
     // ---- S: the tone's bin from a 148-point spectrum of the window's middle nfft samples summed in groups of
     // ov (nfft = 148*ov, so the two frequency grids coincide; the channel filter keeps the signal inside the
