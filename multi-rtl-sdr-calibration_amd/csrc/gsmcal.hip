@@ -1793,6 +1793,15 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
                 t1 > t0 ? (double)(t1 - t0) / 100.0 : 0.0, st0[st0.size() / 2], st0[st0.size() * 9 / 10], st0.back(),
                 en0[en0.size() / 2], en0[en0.size() * 9 / 10]);
         for (int i = 0; i < 15; ++i) if (pc[i]) fprintf(stderr, " [%d->%d] %.1f (n=%d)", i, i + 1, ph[i] / pc[i], pc[i]);
+        fprintf(stderr, "\n    mean time of stamp i after stamp 0:");
+        for (int i = 1; i < 16; ++i) {
+            double a = 0.0; int n = 0;
+            for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
+                const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];
+                if (r[0] && r[i]) { a += ((double)r[i] - (double)r[0]) / 100.0; ++n; }
+            }
+            if (n) fprintf(stderr, " %d:%.1f", i, a / n);
+        }
         fprintf(stderr, "\n");
     }
     return 0;

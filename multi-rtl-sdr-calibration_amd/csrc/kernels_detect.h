@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
 
-__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl, int min_hits);   // kernels_estim.h
+__device__ void d_fine_setup(StreamState* st, int ov, int lvl, int min_hits, int lane);   // kernels_estim.h
 
 // ---- k_coarse_scan: first hit + hop walk of FCCH_coarse_position, one workgroup per stream ----
 // grid S, block 256.  LDS: state copy | 64 twiddles | 4 x 36 hop samples | 2 x 11 x 17 hop powers | snr[mv_len + nwin + 64].
@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         }
     }
     __syncthreads();
-    if (tid == 0 && a.fine_setup_ov > 0) d_fine_setup(st, blockIdx.x, a.fine_setup_ov, 0, a.min_hits);
+    if (tid < 64 && a.fine_setup_ov > 0) d_fine_setup(st, a.fine_setup_ov, 0, a.min_hits, tid);
     __syncthreads();
     CS_STAMP(5);
     {

@@ -321,8 +321,20 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// decision kernels: one thread per stream
+// decision steps: the reference's per-stream control logic between the transforms.  Every function here is called by
+// all 64 lanes of ONE wave with the stream's state in LDS (or, for d_fine_setup at the end of k_coarse_scan, in that
+// kernel's LDS copy).  Control flow is wave-uniform (it depends on the shared state only); the loops over hits / rows
+// of the reference run one element per lane, their `break` / early `return` exits resolved with ballots; scalars are
+// written by lane 0.  A loop that sums floating-point values keeps the reference's order (every lane adds the same
+// LDS values serially).  The integer-valued position grids (acc += 10 or 11 frames, :127-133) are exact in any order.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wsync() {      // lane-to-lane hand-over through LDS inside one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#define LANE0(...) do { if (lane == 0) { __VA_ARGS__; } } while (0)
+__device__ __forceinline__ unsigned long long bits_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
 __device__ __forceinline__ void fine_sentinel(StreamState* st) {
     st->n_fcch = 0; st->fcch_is_sentinel = 1;
     st->sampling_ppm1 = INFINITY; st->carrier_ppm1 = INFINITY;
@@ -330,274 +342,250 @@ __device__ __forceinline__ void fine_sentinel(StreamState* st) {
 }
 
 // FCCH_fine_correction.m:8-46 -- window list for the fine search (level `lvl`)
-__device__ void d_fine_setup(StreamState* st, int s, int ov, int lvl, int min_hits) {
-    (void)s;
-    fine_sentinel(st);
-    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+__device__ void d_fine_setup(StreamState* st, int ov, int lvl, int min_hits, int lane) {
+    LANE0(fine_sentinel(st));
+    if (lane >= 1 && lane < NLEVELS && lane > lvl) { st->op[lane].type = OP_NONE; st->op[lane].n = 0; }
     if (st->status < 0) return;
-    if (st->n_coarse < min_hits) { set_status(st, 0, GSMCAL_S_FEW_HITS); return; }   // :12
+    if (st->n_coarse < min_hits) { LANE0(set_status(st, 0, GSMCAL_S_FEW_HITS)); return; }   // :12
     const long len_s_ov = level_len(st, lvl);
     const long len_s = len_s_ov / ov;                                          // :28
     const int max_offset = 64, len_cw = 148;
-    int cnt = 0;
-    for (int i = 0; i < st->n_coarse && i < MAXH; ++i) {
-        const long position = (long)st->coarse_pos[i];
-        if (position + max_offset > len_s - len_cw + 1) break;                 // :35
-        const long sp = (position - max_offset - 1) * ov + 1;                  // :40,43
-        if (sp < 1) { set_status(st, 0, GSMCAL_E_INDEX); st->n_win = 0; return; }
-        st->win_start[cnt++] = sp - 1;
-    }
-    st->n_win = cnt;
+    const int nc = st->n_coarse < MAXH ? st->n_coarse : MAXH;
+    const bool in = lane < nc;
+    const long position = in ? (long)st->coarse_pos[lane] : 0;
+    const bool brk = in && position + max_offset > len_s - len_cw + 1;         // :35 (the loop stops at the first one)
+    const long sp = (position - max_offset - 1) * ov + 1;                      // :40,43
+    const unsigned long long m_brk = __ballot(brk), m_bad = __ballot(in && sp < 1);
+    const int cnt = m_brk ? __ffsll((long long)m_brk) - 1 : nc;
+    if (m_bad & bits_below(cnt)) { LANE0(set_status(st, 0, GSMCAL_E_INDEX)); return; }   // (n_win stays 0)
+    if (lane < cnt) st->win_start[lane] = sp - 1;
+    LANE0(st->n_win = cnt);
+}
+
+// the reference's spacing test of consecutive positions (FCCH_fine_correction.m:85-93, SCH_corr_rate_correction.m:96-104):
+// bit i of a / b: pos[i+1]-pos[i] within the tolerance of 10 / 11 frames
+__device__ __forceinline__ void spacing_masks(const double* pos, int n, double d_ov, double d1_ov, double max_ppm, int lane,
+                                              unsigned* a_mask, unsigned* b_mask) {
+    const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
+    const bool act = lane < n - 1;
+    const double diff = act ? pos[lane + 1] - pos[lane] : 0.0;
+    *a_mask = (unsigned)__ballot(act && fabs(diff - d_ov) < max_th);
+    *b_mask = (unsigned)__ballot(act && fabs(diff - d1_ov) < max_th1);
+}
+// the regenerated grid (FCCH_fine_correction.m:127-133, SCH_corr_rate_correction.m:135): acc = 1, then + 10 or 11 frames
+// per gap (11 wins where both tests passed); every term is an integer below 2^53, so the sum is exact in any order
+__device__ __forceinline__ double grid_pos(unsigned a_mask, unsigned b_mask, double d_ov, double d1_ov, double first, int lane) {
+    const unsigned below = lane >= 32 ? ~0u : ((1u << lane) - 1u);
+    const double acc = 1.0 + ((double)__popc(a_mask & ~b_mask & below) * d_ov + (double)__popc(b_mask & below) * d1_ov);
+    return acc + first - 1.0;
 }
 
 // FCCH_fine_correction.m:52-137 -- positions, sampling error, new grid, burst windows at level lvl+1
-__device__ void d_fine_decide(StreamState* st, int s, const PeakOut* peaks, int H, int NB, int ov, int lvl, const DevParams& P) {
-    (void)s;
-    if (st->status < 0 || st->stage_status[0] != 0) { st->n_win = 0; return; }
-    const int last_idx = st->n_win;        // fine_first[0..last_idx) was filled by the lanes of k_step
-    (void)peaks; (void)H; (void)NB;
-    st->n_fine = last_idx;
-    st->n_win = 0;
+__device__ void d_fine_decide(StreamState* st, int ov, int lvl, const DevParams& P, int lane) {
+    if (st->status < 0 || st->stage_status[0] != 0) { LANE0(st->n_win = 0); return; }
+    const int last_idx = st->n_win;        // fine_first[0..last_idx) was filled by the lanes of step_body
+    LANE0(st->n_fine = last_idx; st->n_win = 0);
     const int fft_len = 148 * ov;
     if (last_idx < P.min_hits) {                                               // :69 not taken
-        st->fcch_is_sentinel = 0;
-        st->n_fcch = last_idx;
-        for (int w = 0; w < last_idx; ++w) st->fcch_pos[w] = st->fine_first[w];
-        set_status(st, 0, GSMCAL_S_FINE_FEW);
+        if (lane < last_idx) st->fcch_pos[lane] = st->fine_first[lane];
+        LANE0(st->fcch_is_sentinel = 0; st->n_fcch = last_idx; set_status(st, 0, GSMCAL_S_FINE_FEW));
         return;
     }
     const double d_ov = 10.0 * 1250.0 * (double)ov, d1_ov = 11.0 * 1250.0 * (double)ov;   // :80-81
-    const double max_ppm = P.fine_max_ppm;                                                 // :83
-    const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
-    int na = 0, nb = 0;
-    double expected = 0.0;
-    unsigned a_mask = 0, b_mask = 0;
-    for (int i = 0; i < last_idx - 1; ++i) {
-        const double diff = st->fine_first[i + 1] - st->fine_first[i];
-        if (fabs(diff - d_ov) < max_th) { ++na; a_mask |= 1u << i; }
-        if (fabs(diff - d1_ov) < max_th1) { ++nb; b_mask |= 1u << i; }
-    }
+    unsigned a_mask, b_mask;
+    spacing_masks(st->fine_first, last_idx, d_ov, d1_ov, P.fine_max_ppm, lane, &a_mask, &b_mask);   // :83-93
+    const int na = __popc(a_mask), nb = __popc(b_mask);
     if (na + nb != last_idx - 1) {                                             // :95-102
-        st->r1_kind = 1;  // r = s was already assigned (:72)
-        set_status(st, 0, GSMCAL_S_FINE_SPACING);
+        LANE0(st->r1_kind = 1; set_status(st, 0, GSMCAL_S_FINE_SPACING));      // r = s was already assigned (:72)
         return;
     }
-    expected = (double)na * d_ov + (double)nb * d1_ov;                         // :111
+    const double expected = (double)na * d_ov + (double)nb * d1_ov;            // :111
     const double actual = st->fine_first[last_idx - 1] - st->fine_first[0];
     const double e = (actual - expected) / expected;                           // :113
-    st->sampling_ppm1 = e * 1e6;
     const long len_r = level_len(st, lvl);
     const long max_len = e >= 0.0 ? (long)floor((double)len_r / (1.0 + e)) : len_r;   // :118-122
-    st->op[lvl + 1].type = OP_LERP;
-    st->op[lvl + 1].param = 1.0 + e;
-    st->op[lvl + 1].n = max_len;
-    st->r1_kind = 2;
+    LANE0(st->sampling_ppm1 = e * 1e6;
+          st->op[lvl + 1].type = OP_LERP; st->op[lvl + 1].param = 1.0 + e; st->op[lvl + 1].n = max_len;
+          st->r1_kind = 2);
     // :127-133 regenerated grid
     const double first = round((st->fine_first[0] - 1.0) / (1.0 + e)) + 1.0;
-    double acc = 1.0;
+    const double pos = grid_pos(a_mask, b_mask, d_ov, d1_ov, first, lane);
+    if (lane < last_idx) st->fcch_pos[lane] = pos;
     int n = last_idx;
-    st->fcch_pos[0] = acc + first - 1.0;
-    for (int i = 0; i < last_idx - 1; ++i) {
-        double step = 0.0;
-        if (a_mask & (1u << i)) step = d_ov;
-        if (b_mask & (1u << i)) step = d1_ov;
-        acc += step;
-        st->fcch_pos[i + 1] = acc + first - 1.0;
-    }
-    if (st->fcch_pos[n - 1] + (double)fft_len - 1.0 > (double)max_len) --n;  // :135
-    st->n_fcch = n;
-    st->fcch_is_sentinel = 0;
+    if (__shfl(pos, n - 1, 64) + (double)fft_len - 1.0 > (double)max_len) --n;   // :135
+    LANE0(st->n_fcch = n; st->fcch_is_sentinel = 0);
     if (n >= P.min_hits) {                                                     // :142
-        for (int i = 0; i < n; ++i) {
-            const long sp = (long)st->fcch_pos[i];
-            if (sp < 1 || sp + fft_len - 1 > max_len) { set_status(st, 0, GSMCAL_E_INDEX); return; }
-            st->win_start[i] = sp - 1;
-        }
-        st->n_win = n;
+        const long sp = (long)pos;
+        if (__ballot(lane < n && (sp < 1 || sp + fft_len - 1 > max_len))) { LANE0(set_status(st, 0, GSMCAL_E_INDEX)); return; }
+        if (lane < n) st->win_start[lane] = sp - 1;
+        LANE0(st->n_win = n);
     } else {
-        set_status(st, 0, GSMCAL_S_FINE_FEW_BURSTS);
+        LANE0(set_status(st, 0, GSMCAL_S_FINE_FEW_BURSTS));
     }
 }
 
-// mean(fo), carrier ppm and the derotation op; shared by fine (:158-165) and post-SCH (:75-83)
-__device__ __forceinline__ double carrier_from_bursts(StreamState* st, int nb, int ov, double carrier_freq,
-                                                      int op_level, long n, double* ppm) {
+// mean(fo), carrier ppm and the derotation op; shared by fine (:158-165) and post-SCH (:75-83).  (The mean keeps the
+// reference's order of additions: every lane adds the same values.)
+__device__ __forceinline__ void carrier_from_bursts(StreamState* st, int nb, int ov, double carrier_freq,
+                                                    int op_level, long n, double* ppm, int lane) {
     const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
     const double target_freq = GSM_SYMBOL_RATE / 4.0;
     double fo = 0.0;
     for (int i = 0; i < nb; ++i) fo += st->fo_burst[i];
     fo = fo / (double)nb;
-    *ppm = 1e6 * (fo - target_freq) / carrier_freq;
     const double comp_freq = target_freq - fo;
     const double cpr = comp_freq * 2.0 * PI_D / sampling_rate;
-    st->op[op_level].type = OP_MIX;
-    st->op[op_level].param = cpr;
-    st->op[op_level].n = n;
-    return fo;
+    LANE0(*ppm = 1e6 * (fo - target_freq) / carrier_freq;
+          st->op[op_level].type = OP_MIX; st->op[op_level].param = cpr; st->op[op_level].n = n);
 }
 
 // FCCH_fine_correction.m:158-165,192-196
-__device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl, const DevParams& P) {
-    (void)s;
+__device__ void d_carrier_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl, const DevParams& P, int lane) {
     const int nb = st->n_win;
-    st->n_win = 0;
+    LANE0(st->n_win = 0);
     if (nb == 0) return;
-    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 2, st->op[lvl + 1].n, &st->carrier_ppm1);
-    st->r1_kind = 3;
-    int low = 0;
-    for (int i = 0; i < nb; ++i) low += st->snr_burst[i] < P.fine_gate_snr;
-    if (low > 0) {                                                             // :192
-        st->n_fcch = 0;
-        st->fcch_is_sentinel = 1;
-        set_status(st, 0, GSMCAL_S_FINE_LOW_SNR);
-    }
+    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 2, st->op[lvl + 1].n, &st->carrier_ppm1, lane);
+    LANE0(st->r1_kind = 3);
+    if (__ballot(lane < nb && st->snr_burst[lane] < P.fine_gate_snr))          // :192
+        LANE0(st->n_fcch = 0; st->fcch_is_sentinel = 1; set_status(st, 0, GSMCAL_S_FINE_LOW_SNR));
 }
 
 // SCH_corr_rate_correction.m:8-48 -- correlation windows at level lvl
-__device__ void d_sch_setup(StreamState* st, int s, int ov, int len_ts, int lvl, const DevParams& P) {
-    (void)s;
-    st->sch_edge = 0;
-    st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0; st->n_sent_rows = 1;   // :9 pos_info = [-1, -1]
-    st->sampling_ppm2 = INFINITY; st->r2_kind = 0;
-    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+__device__ void d_sch_setup(StreamState* st, int ov, int len_ts, int lvl, const DevParams& P, int lane) {
+    LANE0(st->sch_edge = 0;
+          st->n_win = 0; st->n_sch_first = 0; st->n_sch = 0; st->n_rows = 0; st->n_sent_rows = 1;   // :9 pos_info = [-1, -1]
+          st->sampling_ppm2 = INFINITY; st->r2_kind = 0);
+    if (lane >= 1 && lane < NLEVELS && lane > lvl) { st->op[lane].type = OP_NONE; st->op[lane].n = 0; }
     if (st->status < 0) return;
-    if (st->fcch_is_sentinel || st->n_fcch < P.min_hits) { set_status(st, 1, GSMCAL_S_FEW_HITS); return; }  // :11
+    if (st->fcch_is_sentinel || st->n_fcch < P.min_hits) { LANE0(set_status(st, 1, GSMCAL_S_FEW_HITS)); return; }  // :11
     const long len_s_ov = level_len(st, lvl);
     const long fix_off = (long)((1250 + 42) * ov);       // :26-27
     const long max_offset = 8 * ov;                      // :36
-    int cnt = 0;
-    for (int i = 0; i < st->n_fcch; ++i) {
-        const long training_sp = (long)st->fcch_pos[i] + fix_off;
-        if (training_sp + max_offset > len_s_ov - len_ts + 1) break;           // :40
-        const long sp = training_sp - max_offset;
-        if (sp < 1) { set_status(st, 1, GSMCAL_E_INDEX); return; }
-        st->win_start[cnt++] = sp - 1;
-    }
-    st->n_win = cnt;
+    const int nf = st->n_fcch;
+    const bool in = lane < nf;
+    const long training_sp = in ? (long)st->fcch_pos[lane] + fix_off : 0;
+    const bool brk = in && training_sp + max_offset > len_s_ov - len_ts + 1;   // :40
+    const long sp = training_sp - max_offset;
+    const unsigned long long m_brk = __ballot(brk), m_bad = __ballot(in && sp < 1);
+    const int cnt = m_brk ? __ffsll((long long)m_brk) - 1 : nf;
+    if (m_bad & bits_below(cnt)) { LANE0(set_status(st, 1, GSMCAL_E_INDEX)); return; }
+    if (lane < cnt) st->win_start[lane] = sp - 1;
+    LANE0(st->n_win = cnt);
 }
 
 // SCH_corr_rate_correction.m:59-181
-__device__ void d_sch_decide(StreamState* st, int s, int ov, int lvl, const DevParams& P) {
-    (void)s;
+__device__ void d_sch_decide(StreamState* st, int ov, int lvl, const DevParams& P, int lane) {
     const int num_sch = st->n_win;
-    st->n_win = 0;
+    LANE0(st->n_win = 0);
     if (st->status < 0 || st->stage_status[1] != 0) return;
-    st->n_sch_first = num_sch;
-    if (st->sch_edge) { set_status(st, 1, GSMCAL_S_SCH_EDGE); return; }       // :59-63 pos_info = [-1, -1]
-    st->n_sent_rows = 3 * st->n_fcch;                                          // :32 pos_info = -ones(3*num_fcch_hit, 2) from here on
-    if (num_sch < P.min_hits) { set_status(st, 1, GSMCAL_S_SCH_FEW); return; }   // :84
+    LANE0(st->n_sch_first = num_sch);
+    if (st->sch_edge) { LANE0(set_status(st, 1, GSMCAL_S_SCH_EDGE)); return; }   // :59-63 pos_info = [-1, -1]
+    LANE0(st->n_sent_rows = 3 * st->n_fcch);                                   // :32 pos_info = -ones(3*num_fcch_hit, 2) from here on
+    if (num_sch < P.min_hits) { LANE0(set_status(st, 1, GSMCAL_S_SCH_FEW)); return; }   // :84
     const double frame_ov = 1250.0 * (double)ov, slot_ov = 156.25 * (double)ov;
     const double d_ov = 10.0 * frame_ov, d1_ov = 11.0 * frame_ov;
-    const double max_ppm = P.sch_max_ppm;                                                  // :94
-    const double max_th = floor(d_ov * max_ppm * 1e-6), max_th1 = floor(d1_ov * max_ppm * 1e-6);
-    int na = 0, nb = 0;
-    unsigned a_mask = 0, b_mask = 0;
-    for (int i = 0; i < num_sch - 1; ++i) {
-        const double diff = st->sch_first[i + 1] - st->sch_first[i];
-        if (fabs(diff - d_ov) < max_th) { ++na; a_mask |= 1u << i; }
-        if (fabs(diff - d1_ov) < max_th1) { ++nb; b_mask |= 1u << i; }
-    }
-    st->r2_kind = 1;                                                           // :87 r = s
-    if (na + nb != num_sch - 1) { set_status(st, 1, GSMCAL_S_SCH_SPACING); return; }   // :106-112
+    unsigned a_mask, b_mask;
+    spacing_masks(st->sch_first, num_sch, d_ov, d1_ov, P.sch_max_ppm, lane, &a_mask, &b_mask);   // :94-104
+    const int na = __popc(a_mask), nb = __popc(b_mask);
+    LANE0(st->r2_kind = 1);                                                    // :87 r = s
+    if (na + nb != num_sch - 1) { LANE0(set_status(st, 1, GSMCAL_S_SCH_SPACING)); return; }   // :106-112
     const double expected = (double)na * d_ov + (double)nb * d1_ov;
     const double actual = st->sch_first[num_sch - 1] - st->sch_first[0];
     const double e = (actual - expected) / expected;
-    st->sampling_ppm2 = e * 1e6;
     const long len_in = level_len(st, lvl);
     long len_r = len_in;
-    if (e != 0.0) {                                                            // :120
-        len_r = e > 0.0 ? (long)floor((double)len_in / (1.0 + e)) : len_in;
-        st->op[lvl + 1].type = OP_LERP;
-        st->op[lvl + 1].param = 1.0 + e;
-    } else {
-        st->op[lvl + 1].type = OP_COPY;
-        st->op[lvl + 1].param = 1.0;
-    }
-    st->op[lvl + 1].n = len_r;
-    st->r2_kind = 2;
+    if (e != 0.0) len_r = e > 0.0 ? (long)floor((double)len_in / (1.0 + e)) : len_in;   // :120
+    LANE0(st->sampling_ppm2 = e * 1e6;
+          st->op[lvl + 1].type = e != 0.0 ? OP_LERP : OP_COPY; st->op[lvl + 1].param = e != 0.0 ? 1.0 + e : 1.0;
+          st->op[lvl + 1].n = len_r;
+          st->r2_kind = 2);
     const double first = round((st->sch_first[0] - 1.0) / (1.0 + e)) + 1.0;   // :135
-    double acc = 1.0;
-    st->sch_pos[0] = acc + first - 1.0;
-    for (int i = 0; i < num_sch - 1; ++i) {
-        double step = 0.0;
-        if (a_mask & (1u << i)) step = d_ov;
-        if (b_mask & (1u << i)) step = d1_ov;
-        acc += step;
-        st->sch_pos[i + 1] = acc + first - 1.0;
-    }
-    st->n_sch = num_sch;
-    // :138-141 BCCH_flag (1-based indices 1..num_sch+1)
-    unsigned bcch = 0;
-    for (int i = 0; i < num_sch - 1; ++i)
-        if (b_mask & (1u << i)) {
-            const int b_idx = i + 1;               // 1-based
-            bcch |= 1u << (b_idx + 1);             // BCCH_flag(b_idx+1) = 1
-            if (b_idx >= 5) bcch |= 1u << (b_idx - 4);
-        }
+    const double pos = grid_pos(a_mask, b_mask, d_ov, d1_ov, first, lane);
+    if (lane < num_sch) st->sch_pos[lane] = pos;
+    LANE0(st->n_sch = num_sch);
+    // :138-141 BCCH_flag (1-based indices 1..num_sch+1): an 11-frame gap b_idx = i+1 flags b_idx+1 and, from the fifth on, b_idx-4
+    const unsigned bcch = (b_mask << 2) | ((b_mask & ~0xFu) >> 3);
+    // :143-181 rows of SCH i: its FCCH (type 0), itself (1) if the slot fits, then 4 BCCH slots (2) when flagged, each only
+    // if it fits; the first slot that does not fit ends the whole table
     const double fix_off = (double)((1250 + 42) * ov), pre_ts = (double)(42 * ov);
-    int rows = 0;
-    double* pi0 = st->pos_info;
-    double* pi1 = st->pos_info + MAXROWS;
-    for (int i = 0; i < num_sch; ++i) {
-        double sp = st->sch_pos[i] - fix_off;
-        if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 0.0; }
-        ++rows;
-        sp = st->sch_pos[i] - pre_ts;
-        double ep = sp + slot_ov - 1.0;
-        if (ep <= (double)len_r) {
-            if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 1.0; }
-            ++rows;
-        } else break;
-        const double sch_sp = sp;
-        if (bcch & (1u << (i + 1))) {
-            bool runout = false;
-            for (int idx = 1; idx <= 4; ++idx) {
-                sp = sch_sp + (double)idx * frame_ov;
-                ep = sp + slot_ov - 1.0;
-                if (ep <= (double)len_r) {
-                    if (rows < MAXROWS) { pi0[rows] = sp; pi1[rows] = 2.0; }
-                    ++rows;
-                } else { runout = true; break; }
+    const bool in = lane < num_sch;
+    const double sch_sp = pos - pre_ts;
+    int count = 0;
+    bool complete = true;
+    if (in) {
+        count = 1;
+        if (sch_sp + slot_ov - 1.0 <= (double)len_r) {
+            count = 2;
+            if (bcch & (1u << (lane + 1))) {
+                for (int idx = 1; idx <= 4; ++idx) {
+                    const double sp = sch_sp + (double)idx * frame_ov;
+                    if (complete && sp + slot_ov - 1.0 <= (double)len_r) ++count; else complete = false;
+                }
             }
-            if (runout) break;
-        }
+        } else complete = false;
     }
-    if (rows > MAXROWS) { set_status(st, 1, GSMCAL_E_CAPACITY); rows = 0; }
-    st->n_rows = rows;
+    const unsigned long long m_inc = __ballot(in && !complete);
+    const int last = m_inc ? __ffsll((long long)m_inc) - 1 : num_sch - 1;     // the last SCH that contributes rows
+    if (lane > last) count = 0;
+    int incl = count;
+    for (int off = 1; off < 32; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    int rows = __shfl(incl, last, 64);
+    if (rows > MAXROWS) {
+        LANE0(set_status(st, 1, GSMCAL_E_CAPACITY));
+        rows = 0;
+    } else if (count > 0) {
+        double* pi0 = st->pos_info + (incl - count);
+        double* pi1 = pi0 + MAXROWS;
+        pi0[0] = pos - fix_off; pi1[0] = 0.0;
+        if (count >= 2) { pi0[1] = sch_sp; pi1[1] = 1.0; }
+        for (int idx = 1; idx <= 4; ++idx)
+            if (count >= 2 + idx) { pi0[1 + idx] = sch_sp + (double)idx * frame_ov; pi1[1 + idx] = 2.0; }
+    }
+    LANE0(st->n_rows = rows);
 }
 
 // carrier_correct_post_SCH.m:8-62 -- FCCH-row windows at level lvl
-__device__ void d_post_setup(StreamState* st, int s, int ov, int lvl, const DevParams& P) {
-    (void)s;
-    st->n_win = 0; st->carrier_ppm2 = INFINITY; st->r3_kind = 0;
-    for (int j = 1; j < NLEVELS; ++j) if (j > lvl) { st->op[j].type = OP_NONE; st->op[j].n = 0; }
+__device__ void d_post_setup(StreamState* st, int ov, int lvl, const DevParams& P, int lane) {
+    LANE0(st->n_win = 0; st->carrier_ppm2 = INFINITY; st->r3_kind = 0);
+    if (lane >= 1 && lane < NLEVELS && lane > lvl) { st->op[lane].type = OP_NONE; st->op[lane].n = 0; }
     if (st->status < 0) return;
-    if (st->n_rows == 0) { set_status(st, 2, GSMCAL_S_POST_NO_POS); return; }  // :10
+    const int n_rows = st->n_rows;
+    if (n_rows == 0) { LANE0(set_status(st, 2, GSMCAL_S_POST_NO_POS)); return; }  // :10
     const double* pi0 = st->pos_info;
     const double* pi1 = st->pos_info + MAXROWS;
     int nb = 0;
-    for (int i = 0; i < st->n_rows; ++i) nb += pi1[i] == 2.0;
-    if (nb < P.post_min_bcch) { set_status(st, 2, GSMCAL_S_POST_FEW_BCCH); return; }   // :15-19
+    for (int r0 = 0; r0 < n_rows; r0 += 64) nb += __popcll(__ballot(r0 + lane < n_rows && pi1[r0 + lane] == 2.0));
+    if (nb < P.post_min_bcch) { LANE0(set_status(st, 2, GSMCAL_S_POST_FEW_BCCH)); return; }   // :15-19
     const int fft_len = 148 * ov;
     const long len = level_len(st, lvl);
     int cnt = 0;
-    for (int i = 0; i < st->n_rows; ++i)
-        if (pi1[i] == 0.0) {
-            const long sp = (long)pi0[i];
-            if (sp < 1 || sp + fft_len - 1 > len || cnt >= MAXH) { set_status(st, 2, GSMCAL_E_INDEX); return; }
-            st->win_start[cnt++] = sp - 1;
+    bool bad = false;
+    for (int r0 = 0; r0 < n_rows; r0 += 64) {
+        const int r = r0 + lane;
+        const bool is0 = r < n_rows && pi1[r] == 0.0;
+        const unsigned long long m = __ballot(is0);
+        const int idx = cnt + __popcll(m & bits_below(lane));
+        const long sp = is0 ? (long)pi0[r] : 1;
+        if (is0) {
+            if (sp < 1 || sp + fft_len - 1 > len || idx >= MAXH) bad = true;
+            else st->win_start[idx] = sp - 1;
         }
-    st->n_win = cnt;
+        cnt += __popcll(m);
+    }
+    if (__ballot(bad)) { LANE0(set_status(st, 2, GSMCAL_E_INDEX)); return; }
+    LANE0(st->n_win = cnt);
 }
 
 // carrier_correct_post_SCH.m:75-83
-__device__ void d_post_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl) {
-    (void)s;
+__device__ void d_post_decide(StreamState* st, int s, int ov, const double* carrier_freq, int lvl, int lane) {
     const int nb = st->n_win;
-    st->n_win = 0;
+    LANE0(st->n_win = 0);
     if (nb == 0) return;
-    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 1, level_len(st, lvl), &st->carrier_ppm2);
-    st->r3_kind = 3;
+    carrier_from_bursts(st, nb, ov, carrier_freq[s], lvl + 1, level_len(st, lvl), &st->carrier_ppm2, lane);
+    LANE0(st->r3_kind = 3);
 }
 
 // total_ppm_calculation.m:5-21
@@ -607,52 +595,55 @@ __host__ __device__ inline double total_ppm(double a, double b) {
 }
 
 // gsm_sync_demod.m:123-124 + table row
-__device__ void d_totals(const StreamState* st, int s, double* table, double* pos_info_out, long* r_len_out) {
-    double* row = table + (size_t)s * GSMCAL_TABLE_COLS;
-    row[GSMCAL_T_SAMPLING_PPM_FCCH] = st->sampling_ppm1;
-    row[GSMCAL_T_SAMPLING_PPM_SCH] = st->sampling_ppm2;
-    row[GSMCAL_T_CARRIER_PPM_FCCH] = st->carrier_ppm1;
-    row[GSMCAL_T_CARRIER_PPM_POST] = st->carrier_ppm2;
-    row[GSMCAL_T_TOTAL_SAMPLING_PPM] = total_ppm(st->sampling_ppm1, st->sampling_ppm2);
-    row[GSMCAL_T_TOTAL_CARRIER_PPM] = total_ppm(st->carrier_ppm1, st->carrier_ppm2);
-    row[GSMCAL_T_N_FCCH] = st->fcch_is_sentinel ? 1.0 : (double)st->n_fcch;
-    row[GSMCAL_T_N_POS_ROWS] = st->n_rows == 0 ? (double)(st->n_sent_rows > 0 ? st->n_sent_rows : 1) : (double)st->n_rows;
-    row[GSMCAL_T_FIRST_FCCH_POS] = st->n_rows == 0 ? -1.0 : st->pos_info[0];
-    row[GSMCAL_T_STATUS] = (double)st->status;
+__device__ void d_totals(const StreamState* st, int s, double* table, double* pos_info_out, long* r_len_out, int lane) {
+    if (lane == 0) {
+        double* row = table + (size_t)s * GSMCAL_TABLE_COLS;
+        row[GSMCAL_T_SAMPLING_PPM_FCCH] = st->sampling_ppm1;
+        row[GSMCAL_T_SAMPLING_PPM_SCH] = st->sampling_ppm2;
+        row[GSMCAL_T_CARRIER_PPM_FCCH] = st->carrier_ppm1;
+        row[GSMCAL_T_CARRIER_PPM_POST] = st->carrier_ppm2;
+        row[GSMCAL_T_TOTAL_SAMPLING_PPM] = total_ppm(st->sampling_ppm1, st->sampling_ppm2);
+        row[GSMCAL_T_TOTAL_CARRIER_PPM] = total_ppm(st->carrier_ppm1, st->carrier_ppm2);
+        row[GSMCAL_T_N_FCCH] = st->fcch_is_sentinel ? 1.0 : (double)st->n_fcch;
+        row[GSMCAL_T_N_POS_ROWS] = st->n_rows == 0 ? (double)(st->n_sent_rows > 0 ? st->n_sent_rows : 1) : (double)st->n_rows;
+        row[GSMCAL_T_FIRST_FCCH_POS] = st->n_rows == 0 ? -1.0 : st->pos_info[0];
+        row[GSMCAL_T_STATUS] = (double)st->status;
+        if (r_len_out) r_len_out[s] = st->r3_kind == 3 ? st->op[4].n : -1;
+    }
     if (pos_info_out) {
         double* o = pos_info_out + (size_t)s * 2 * MAXROWS;
-        for (int i = 0; i < 2 * MAXROWS; ++i) o[i] = -1.0;
-        for (int i = 0; i < st->n_rows; ++i) { o[i] = st->pos_info[i]; o[MAXROWS + i] = st->pos_info[MAXROWS + i]; }
+        const int n_rows = st->n_rows;
+        for (int i = lane; i < 2 * MAXROWS; i += 64) o[i] = (i < MAXROWS ? i : i - MAXROWS) < n_rows ? st->pos_info[i] : -1.0;
     }
-    if (r_len_out) r_len_out[s] = st->r3_kind == 3 ? st->op[4].n : -1;
 }
 
 // multi_rtl_sdr_gsm_FCCH_scanner.m:168-185 acceptance -> (snr, num_hit) per capture
 __device__ void d_scan_accept(const StreamState* st, int s, double* snr_numhit, double* positions,
-                              double* pos_snr, int* counts, const DevParams& P) {
+                              double* pos_snr, int* counts, const DevParams& P, int lane) {
     const int n = st->n_coarse;
     double snr = 0.0, num_hit = 0.0;
     if (n >= P.scan_min_hits) {
-        bool ok = true;
-        for (int i = 0; i < n - 1 && ok; ++i) {
-            const double d = st->coarse_pos[i + 1] - st->coarse_pos[i];
-            if (fabs(d - P.scan_spacing) > P.scan_tol) ok = !(fabs(d - P.scan_spacing_idle) > P.scan_tol);
+        bool fail = false;
+        if (lane < n - 1) {
+            const double d = st->coarse_pos[lane + 1] - st->coarse_pos[lane];
+            fail = fabs(d - P.scan_spacing) > P.scan_tol && fabs(d - P.scan_spacing_idle) > P.scan_tol;
         }
-        if (ok) {
+        if (!__ballot(fail)) {
             double sum = 0.0;
             for (int i = 0; i < n; ++i) sum += st->coarse_snr[i];
             snr = sum / (double)n;
             num_hit = (double)n;
         }
     }
-    snr_numhit[2 * s] = snr;
-    snr_numhit[2 * s + 1] = num_hit;
-    if (counts) counts[s] = n;
-    if (positions)
-        for (int i = 0; i < MAXH; ++i) {
-            positions[(size_t)s * MAXH + i] = i < n ? st->coarse_pos[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
-            if (pos_snr) pos_snr[(size_t)s * MAXH + i] = i < n ? st->coarse_snr[i] : (n == 0 && i == 0 ? -1.0 : 0.0);
-        }
+    if (lane == 0) {
+        snr_numhit[2 * s] = snr;
+        snr_numhit[2 * s + 1] = num_hit;
+        if (counts) counts[s] = n;
+    }
+    if (positions && lane < MAXH) {
+        positions[(size_t)s * MAXH + lane] = lane < n ? st->coarse_pos[lane] : (n == 0 && lane == 0 ? -1.0 : 0.0);
+        if (pos_snr) pos_snr[(size_t)s * MAXH + lane] = lane < n ? st->coarse_snr[lane] : (n == 0 && lane == 0 ? -1.0 : 0.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -713,16 +704,16 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
     }
     if (steps & STEP_FINE_DECIDE) __syncthreads();
     TAIL_STAMP(10);
-    if (lane == 0) {
-        if (steps & STEP_FINE_SETUP) d_fine_setup(sh, s, a.ov, lvl_a, a.P.min_hits);
-        if (steps & STEP_FINE_DECIDE) d_fine_decide(sh, s, a.peaks, a.H, a.NB, a.ov, lvl_a, a.P);
-        if (steps & STEP_CARRIER_DECIDE) d_carrier_decide(sh, s, a.ov, a.carrier_freq, lvl_a, a.P);
-        if (steps & STEP_SCH_SETUP) d_sch_setup(sh, s, a.ov, a.len_ts, lvl_b, a.P);
-        if (steps & STEP_SCH_DECIDE) d_sch_decide(sh, s, a.ov, lvl_a, a.P);
-        if (steps & STEP_POST_SETUP) d_post_setup(sh, s, a.ov, lvl_b, a.P);
-        if (steps & STEP_POST_DECIDE) d_post_decide(sh, s, a.ov, a.carrier_freq, lvl_a);
-        if (steps & STEP_TOTALS) d_totals(sh, s, a.table, a.pos_info_out, a.r_len_out);
-        if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts, a.P);
+    if (lane < 64) {      // one wave; wsync() hands each step's LDS writes to the next step's lanes
+        if (steps & STEP_FINE_SETUP) { d_fine_setup(sh, a.ov, lvl_a, a.P.min_hits, lane); wsync(); }
+        if (steps & STEP_FINE_DECIDE) { d_fine_decide(sh, a.ov, lvl_a, a.P, lane); wsync(); }
+        if (steps & STEP_CARRIER_DECIDE) { d_carrier_decide(sh, s, a.ov, a.carrier_freq, lvl_a, a.P, lane); wsync(); }
+        if (steps & STEP_SCH_SETUP) { d_sch_setup(sh, a.ov, a.len_ts, lvl_b, a.P, lane); wsync(); }
+        if (steps & STEP_SCH_DECIDE) { d_sch_decide(sh, a.ov, lvl_a, a.P, lane); wsync(); }
+        if (steps & STEP_POST_SETUP) { d_post_setup(sh, a.ov, lvl_b, a.P, lane); wsync(); }
+        if (steps & STEP_POST_DECIDE) { d_post_decide(sh, s, a.ov, a.carrier_freq, lvl_a, lane); wsync(); }
+        if (steps & STEP_TOTALS) d_totals(sh, s, a.table, a.pos_info_out, a.r_len_out, lane);
+        if (steps & STEP_SCAN_ACCEPT) d_scan_accept(sh, s, a.snr_numhit, a.positions, a.pos_snr, a.counts, a.P, lane);
     }
     __syncthreads();
     TAIL_STAMP(11);

@@ -606,53 +606,77 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     unsigned short* r_s = (unsigned short*)(smem + gc.off_raw);
     const StreamState* st = sts + s;
     const int level = a.level;
-    // every state field used below, fetched with independent loads up front: the range logic is a chain of small
-    // decisions, and one round trip to L2 per decision (~0.5 us each) was a quarter of this function's time
-    const int pre_nwin = st->n_win;
-    const long pre_n0 = st->n0;
-    const long pre_ws = (!a.tiles && widx >= 0 && widx < MAXH) ? st->win_start[widx] : 0;
-    const double pre_mr = st->mean_re, pre_mi = st->mean_im;
-    int op_type[NLEVELS];
-    double op_param[NLEVELS];
-    long lvl_n[NLEVELS];
-    lvl_n[0] = pre_n0; op_type[0] = OP_NONE; op_param[0] = 0.0;
+    const int tid = threadIdx.x;
+    // The plan of this window -- where it starts and which range of every lower level it needs -- is a chain of small
+    // dependent decisions on a handful of state fields.  Only the first wave works it out (every field fetched with
+    // independent loads up front; one round trip to L2 per decision was a quarter of this function's time) and hands it
+    // to the others through LDS: NT/64 waves stepping through the same serial code only compete for the issue slots.
+    __shared__ long pl_lo[NLEVELS], pl_hi[NLEVELS], pl_n0, pl_start;
+    __shared__ double pl_param[NLEVELS], pl_mr, pl_mi;
+    __shared__ int pl_type[NLEVELS], pl_L;
+    // ... which meanwhile fetch the filter taps
+    if (a.src_kind != SRC_ARR && NT > 64 && tid >= 64)
+        for (int i = tid - 64; i < a.ntaps; i += NT - 64) c_s[i] = a.coef[i];
+    if (tid < 64) {
+        const int pre_nwin = st->n_win;
+        const long pre_n0 = st->n0;
+        const long pre_ws = (!a.tiles && widx >= 0 && widx < MAXH) ? st->win_start[widx] : 0;
+        const double pre_mr = st->mean_re, pre_mi = st->mean_im;
+        int op_type[NLEVELS];
+        double op_param[NLEVELS];
+        long lvl_n[NLEVELS];
+        lvl_n[0] = pre_n0; op_type[0] = OP_NONE; op_param[0] = 0.0;
 #pragma unroll
-    for (int j = 1; j < NLEVELS; ++j) { op_type[j] = st->op[j].type; op_param[j] = st->op[j].param; lvl_n[j] = st->op[j].n; }
-    long start, L;
-    cplx* dst;
-    if (a.tiles) {
-        const long nq = lvl_n[level];
-        start = (long)widx * a.len;
-        if (start >= nq) return nullptr;
-        L = nq - start < a.len ? nq - start : a.len;
-        dst = a.dst + (size_t)s * a.dst_stream_stride + start;
-    } else {
-        if (widx >= pre_nwin) return nullptr;
-        start = pre_ws;
-        L = a.len;
-        dst = a.dst + (size_t)s * a.dst_stream_stride + (size_t)widx * a.dst_win_stride;
-    }
-    // backward range propagation
-    long lo[NLEVELS], hi[NLEVELS];
-    lo[level] = start;
-    hi[level] = start + L - 1;
-    for (int j = level; j >= 1; --j) {
-        if (op_type[j] == OP_LERP) {
-            const double f = op_param[j];
-            const long nprev = lvl_n[j - 1];
-            lo[j - 1] = (long)floor((double)lo[j] * f);
-            long h = (long)floor((double)hi[j] * f) + 1;
-            hi[j - 1] = h > nprev - 1 ? nprev - 1 : h;
-        } else {
-            lo[j - 1] = lo[j];
-            hi[j - 1] = hi[j];
+        for (int j = 1; j < NLEVELS; ++j) { op_type[j] = st->op[j].type; op_param[j] = st->op[j].param; lvl_n[j] = st->op[j].n; }
+#ifdef GSMCAL_DEVTIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        GC_STAMP(14);
+#endif
+        long start = 0, L = 0;
+        if (a.tiles) {
+            const long nq = lvl_n[level];
+            start = (long)widx * a.len;
+            L = start >= nq ? 0 : (nq - start < a.len ? nq - start : a.len);
+        } else if (widx < pre_nwin) {
+            start = pre_ws;
+            L = a.len;
+        }
+        // backward range propagation
+        long clo = start, chi = start + L - 1;
+#pragma unroll
+        for (int j = NLEVELS - 1; j >= 1; --j) {
+            if (j <= level) {
+                if (tid == 0) { pl_lo[j] = clo; pl_hi[j] = chi; }
+                if (op_type[j] == OP_LERP) {
+                    const double f = op_param[j];
+                    const long nprev = lvl_n[j - 1];
+                    clo = (long)floor((double)clo * f);
+                    const long h = (long)floor((double)chi * f) + 1;
+                    chi = h > nprev - 1 ? nprev - 1 : h;
+                }
+            }
+        }
+        if (tid == 0) {
+            pl_lo[0] = clo; pl_hi[0] = chi;
+            pl_n0 = pre_n0; pl_start = start; pl_L = (int)L; pl_mr = pre_mr; pl_mi = pre_mi;
+#pragma unroll
+            for (int j = 1; j < NLEVELS; ++j) { pl_type[j] = op_type[j]; pl_param[j] = op_param[j]; }
         }
     }
+    if (a.src_kind != SRC_ARR && NT <= 64)
+        for (int i = tid; i < a.ntaps; i += NT) c_s[i] = a.coef[i];
+    GC_STAMP(15);
+    __syncthreads();
+    const int L = pl_L;
+    if (L <= 0) return nullptr;                          // block-uniform: no window for this block
+    const long start = pl_start, pre_n0 = pl_n0;
+    const double pre_mr = pl_mr, pre_mi = pl_mi;
+    cplx* dst = a.tiles ? a.dst + (size_t)s * a.dst_stream_stride + start
+                        : a.dst + (size_t)s * a.dst_stream_stride + (size_t)widx * a.dst_win_stride;
     // ---- level 0 ----
-    const long lo0 = lo[0], hi0 = hi[0];
+    const long lo0 = pl_lo[0], hi0 = pl_hi[0];
     const int cnt0 = (int)(hi0 - lo0 + 1);
     cplx* out0 = (level == 0 && !to_lds) ? dst : buf0;
-    const int tid = threadIdx.x;
     if (a.src_kind == SRC_ARR) {
         const cplx* x = a.arr + (size_t)s * a.arr_stride;
         const long n0 = pre_n0;
@@ -666,7 +690,6 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         const int ntp = a.ntaps;
         const long first = lo0 - (ntp - 1);
         const int span = cnt0 + ntp - 1;
-        for (int i = tid; i < ntp; i += NT) c_s[i] = a.coef[i];
         GC_STAMP(9);
         const long first_al = stage_raw(r_s, base, n0, first, span, tid, NT);
         __syncthreads();
@@ -732,13 +755,14 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     for (int j = 1; j <= level; ++j) {
         __syncthreads();
         cplx* o = (j == level && !to_lds) ? dst : other;
-        const int cnt = (int)(hi[j] - lo[j] + 1);
-        const int type = op_type[j];
-        const double p = op_param[j];
-        const long plo = lo[j - 1], phi_ = hi[j - 1];
+        const long lo_j = pl_lo[j];
+        const int cnt = (int)(pl_hi[j] - lo_j + 1);
+        const int type = pl_type[j];
+        const double p = pl_param[j];
+        const long plo = pl_lo[j - 1], phi_ = pl_hi[j - 1];
         if (type == OP_LERP) {
             for (int i = threadIdx.x; i < cnt; i += NT) {
-                const long k = lo[j] + i;
+                const long k = lo_j + i;
                 const double xq = (double)k * p;            // interp_seq = (0:max_len-1)'.*(1+e)
                 const long i0 = (long)floor(xq);
                 const long i1 = i0 + 1 > phi_ ? phi_ : i0 + 1;  // beyond the last sample the weight is 0
@@ -754,7 +778,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             cplx* T = (cplx*)(smem + gc.off_rot);
             const int na = (cnt + 31) >> 5;
             for (int i = threadIdx.x; i < 1 + na + 32; i += NT) {
-                const double arg = i == 0 ? (double)lo[j] * p : (i <= na ? (double)(32 * (i - 1)) * p : (double)(i - 1 - na) * p);
+                const double arg = i == 0 ? (double)lo_j * p : (i <= na ? (double)(32 * (i - 1)) * p : (double)(i - 1 - na) * p);
                 double sn, cs;
                 sincos_large(arg, &sn, &cs);
                 T[i == 0 ? 0 : (i <= na ? i : 1 + GC_ROT_A + (i - 1 - na))] = make_double2(cs, sn);
@@ -764,7 +788,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
                 o[i] = cmul(src[i], cmul(cmul(T[0], T[1 + (i >> 5)]), T[1 + GC_ROT_A + (i & 31)]));
         } else if (type == OP_MIX) {
             for (int i = threadIdx.x; i < cnt; i += NT) {
-                const long k = lo[j] + i;
+                const long k = lo_j + i;
                 double sn, cs;
                 sincos_large((double)k * p, &sn, &cs);      // exp(1i*(0:len-1)'*comp_phase_rotate): k*p rounded once
                 o[i] = cmul(src[i], make_double2(cs, sn));
