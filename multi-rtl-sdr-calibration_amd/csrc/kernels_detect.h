@@ -966,11 +966,11 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 
 // X_k at one shift by a direct fp64 DFT over the nfft samples xw[0..nfft), executed by one wave: lane l sums
 // the terms n = l, l+64, ... (fixed order), then a shuffle tree adds the 64 partials.  The 19 table loads of a
-// pass are independent and issued together (the twiddle table lives in L2).  Returns the value in lane 0.
+// pass are independent and issued together (the twiddle table lives in L2).  Returns the value in every lane.
 __device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __restrict__ tw_g, int nfft, int lane) {
     double ar = 0.0, ai = 0.0;
-    const int stp = (int)(((long)k * 64) % nfft);
-    int idx = (int)(((long)k * lane) % nfft);
+    const int stp = (int)(((unsigned)k * 64u) % (unsigned)nfft);          // (k < nfft <= 2^24: no overflow)
+    int idx = (int)(((unsigned)k * (unsigned)lane) % (unsigned)nfft);
     for (int n0 = 0; n0 < nfft; n0 += 19 * 64) {
         cplx t[19];
         int id = idx;
@@ -991,11 +991,7 @@ __device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        ar += __shfl_down(ar, off, 64);
-        ai += __shfl_down(ai, off, 64);
-    }
-    return make_double2(ar, ai);
+    return make_double2(wave_sum(ar), wave_sum(ai));
 }
 
 // result of k_fine_cert for one window (see below)
@@ -1263,20 +1259,18 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
                 const int k = items[i] >> 8, c = items[i] & 0xFF;
                 const int t0 = c * FS_CHUNK;
                 const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
-                const double a0r = __shfl(av.x, 0, 64), a0i = __shfl(av.y, 0, 64);
+                const double a0r = av.x, a0i = av.y;
                 const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
                 double sr = 0.0, si = 0.0;
                 if (lane < lim) {
                     const cplx xa = xs[t0 + lane + nfft], xb = xs[t0 + lane];
-                    const cplx t = tw_g[(int)(((long)k * lane) % nfft)];
+                    const cplx t = tw_g[((unsigned)k * (unsigned)lane) % (unsigned)nfft];
                     const double dr = xa.x - xb.x, di = xa.y - xb.y;
                     sr = dr * t.x - di * t.y;
                     si = dr * t.y + di * t.x;
                 }
-                for (int off = 1; off < 64; off <<= 1) {                 // inclusive scan: lane m ends with S_(m+1)
-                    const double orr = __shfl_up(sr, off, 64), oi = __shfl_up(si, off, 64);
-                    if (lane >= off) { sr += orr; si += oi; }
-                }
+                sr = wave_scan_incl(sr);                                 // inclusive scan: lane m ends with S_(m+1)
+                si = wave_scan_incl(si);
                 if (lane < lim) {
                     const double xr = a0r + sr, xi = a0i + si;
                     const double p = xr * xr + xi * xi;

@@ -86,6 +86,10 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     cplx* w37 = (cplx*)(smem + gc.total);
     cplx* wN2 = w37 + 40;
     double* P = (double*)(wN2 + N2);
+    // the nfft-point twiddle table, staged in the idle buffer B until B is needed (the candidate DFTs and the rotation
+    // below index it data-dependently: from global memory every step of those loops was a round trip to L2)
+    cplx* twl = B;
+    for (int n = tid; n < nfft; n += BT_THREADS) twl[n] = tw_g[n];
     fft37_tables(w37, wN2, N2, tid, tw_g);
     __syncthreads();
     // ---- spectrum argmax, first max in fftshift order (:149-150) ----
@@ -98,7 +102,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     {
         double e = 0.0;
         for (int n = tid; n < nfft; n += BT_THREADS) { const cplx v = xs[n]; e = fma(v.x, v.x, fma(v.y, v.y, e)); }
-        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+        e = wave_sum(e);
         if ((tid & 63) == 0) red[tid >> 6] = e;
         const int wave = tid >> 6, lane = tid & 63;
         const int prior = prior_mode == 1 ? st->prior_bin[w] : nfft / 32;       // 37 for every oversampling ratio
@@ -106,20 +110,18 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
             int k = prior - 3 + wave;
             k = ((k % nfft) + nfft) % nfft;
             double ar = 0.0, ai = 0.0;
-            int idx = (int)(((long)k * lane) % nfft);
-            const int stp = (int)(((long)k * 64) % nfft);
+            int idx = (int)(((unsigned)k * (unsigned)lane) % (unsigned)nfft);      // (k < nfft <= 2^24: no overflow)
+            const int stp = (int)(((unsigned)k * 64u) % (unsigned)nfft);
 #pragma unroll 4
             for (int n = lane; n < nfft; n += 64) {
-                const cplx v = xs[n], t = tw_g[idx];
+                const cplx v = xs[n], t = twl[idx];
                 ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
                 ai = fma(v.x, t.y, fma(v.y, t.x, ai));
                 idx += stp;
                 if (idx >= nfft) idx -= nfft;
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                ar += __shfl_down(ar, off, 64);
-                ai += __shfl_down(ai, off, 64);
-            }
+            ar = wave_sum(ar);
+            ai = wave_sum(ai);
             if (lane == 0) { red_p[wave] = ar * ar + ai * ai; red_t[wave] = (k + nfft / 2) % nfft; }
         }
         __syncthreads();
@@ -137,7 +139,8 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         }
         __syncthreads();
     }
-    if (sh_key < 0) {                                              // block-uniform: proof failed, full spectrum
+    const bool full = sh_key < 0;
+    if (full) {                                                    // block-uniform: proof failed, full spectrum (B: table gone)
         fft37_step1(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);
         __syncthreads();
         double best = -1.0;
@@ -174,9 +177,10 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     {
         const int jb = max_idx - (nfft / 2 + 1);
         const int jm = jb < 0 ? jb + nfft : jb;
-        for (int n = tid; n < nfft; n += BT_THREADS) {
-            const cplx t = tw_g[(int)(((long)n * jm) % nfft)];
-            xs[n] = cmul(xs[n], t);
+        if (full) {
+            for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], tw_g[((unsigned)n * (unsigned)jm) % (unsigned)nfft]);
+        } else {
+            for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], twl[((unsigned)n * (unsigned)jm) % (unsigned)nfft]);
         }
     }
     __syncthreads();
@@ -196,10 +200,8 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         sr += ua.x * ub.x + ua.y * ub.y;
         si += ua.y * ub.x - ua.x * ub.y;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        sr += __shfl_down(sr, off, 64);
-        si += __shfl_down(si, off, 64);
-    }
+    sr = wave_sum(sr);
+    si = wave_sum(si);
     if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sr; red[2 * (tid >> 6) + 1] = si; }
     __syncthreads();
     if (tid == 0) {
@@ -247,7 +249,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         // added by one wave (a tree instead of a serial loop: the value moves by ~1e-16 relative, it feeds a 5 dB gate)
         double noi = 0.0;
         for (int k = 3 + tid; k < nb - 2; k += 64) noi += P[k];
-        for (int off = 32; off > 0; off >>= 1) noi += __shfl_down(noi, off, 64);
+        noi = wave_sum(noi);
         if (tid == 0) {
             double sig = 0.0;
             for (int k = 0; k < 3; ++k) sig += P[k];

@@ -27,6 +27,37 @@ __device__ __forceinline__ void sincos_large(double t, double* sn, double* cs) {
     sincos(y, sn, cs);
 }
 
+// Sum of v over the 64 lanes of the wave, returned in every lane (wave-uniform).  Data-parallel-primitive moves instead of
+// LDS-crossbar shuffles: xor 1, xor 2, half-row mirror, row mirror give every lane its 16-lane row total; row_bcast15 /
+// row_bcast31 (GFX9) chain the four rows into lane 63.  ~20 VALU instructions, no LDS traffic, no s_waitcnt.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move_f64<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141, 0xF>(v);     // row_half_mirror
+    v += dpp_move_f64<0x140, 0xF>(v);     // row_mirror
+    v += dpp_move_f64<0x142, 0xA>(v);     // row_bcast15 into rows 1 and 3 (other rows add 0)
+    v += dpp_move_f64<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// Inclusive prefix sum over the lanes of the wave (lane l gets v_0 + ... + v_l): row_shr 1, 2, 4, 8 inside the 16-lane
+// rows, then the two row broadcasts.
+__device__ __forceinline__ double wave_scan_incl(double v) {
+    v += dpp_move_f64<0x111, 0xF>(v);
+    v += dpp_move_f64<0x112, 0xF>(v);
+    v += dpp_move_f64<0x114, 0xF>(v);
+    v += dpp_move_f64<0x118, 0xF>(v);
+    v += dpp_move_f64<0x142, 0xA>(v);
+    v += dpp_move_f64<0x143, 0xC>(v);
+    return v;
+}
+
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
