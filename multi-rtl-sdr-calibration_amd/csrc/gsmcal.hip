@@ -82,6 +82,9 @@ struct gsmcal_ctx {
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
+    bool snr_full = true;           // GSMCAL_SNR_FULL=0: the hop walk of FCCH_coarse_position computes its own 16-point spectra
+    double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
+                                    // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
     bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
@@ -583,10 +586,24 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     const long nwin = n_first - (fft_len - 1);
     const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
-    RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * nwin * sizeof(double)));
-    a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = nwin;
-    const dim3 sgrid((unsigned)((nwin + 255) / 256), S);
-    if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, sgrid, dim3(256), 0, a); else LAUNCH(c, k_coarse_snr<false>, sgrid, dim3(256), 0, a);
+    // latency path (few streams, one workgroup per CU at most): k_coarse_snr fills in every window of the stream and the hop
+    // walk of k_coarse_scan becomes table look-ups; big batches keep the table to the moving search's windows
+    long ntab = nwin;
+    unsigned sblocks = (unsigned)((nwin + 255) / 256);
+    if (fft_len == 16 && S <= c->n_cu && c->snr_full && len - (fft_len - 1) > nwin) {
+        ntab = len - (fft_len - 1);
+        a.snr_nwin = ntab;
+        a.snr_screen_db = c->snr_screen_db;
+        const long rest = ntab - nwin;
+        if ((rest + sblocks - 1) / sblocks > CS_TILE - 3) sblocks = (unsigned)((rest + CS_TILE - 4) / (CS_TILE - 3));
+        a.snr_tile = (int)((((rest + sblocks - 1) / sblocks) + 3) & ~3L);
+    }
+    RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * ntab * sizeof(double)));
+    a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = ntab;
+    const dim3 sgrid(sblocks, S);
+    if (fft_len == 16 && a.snr_nwin > 0) LAUNCH(c, (k_coarse_snr<true, true>), sgrid, dim3(CS_SNR_THREADS), 0, a);
+    else if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, sgrid, dim3(256), 0, a);
+    else LAUNCH(c, k_coarse_snr<false>, sgrid, dim3(256), 0, a);
     // register budgets of the same kernel: small batches run one workgroup per CU anyway, big ones want four
     if (fft_len != 16) LAUNCH(c, k_coarse_scan_gen, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     else if (S <= 512) LAUNCH(c, k_coarse_scan_lat, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
@@ -824,6 +841,10 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (lm && atoi(lm) >= 1) c->lane_min = atoi(lm);
     const char* ce = getenv("GSMCAL_CERT");
     if (ce) c->certify = atoi(ce) != 0;
+    const char* sfe = getenv("GSMCAL_SNR_FULL");
+    if (sfe) c->snr_full = atoi(sfe) != 0;
+    const char* sse = getenv("GSMCAL_SNR_SCREEN_DB");
+    if (sse) c->snr_screen_db = atof(sse);
     const char* fge = getenv("GSMCAL_FUSE_GATHER");
     if (fge) c->fuse_fine_gather = atoi(fge) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");

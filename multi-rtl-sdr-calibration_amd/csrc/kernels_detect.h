@@ -90,6 +90,18 @@ __device__ __forceinline__ cplx dv_load(const DecView& v, long j) {
 // 16 samples from `start`.  The DC term of the batch path (DecView) is a constant over the window, and the DFT of a
 // constant lives in bin 0 alone, so it is removed there (X[0] -= 16 c) instead of from every sample.  NOT valid for
 // the few windows that still overlap filter()'s zero initial state (start < v.n_head): see window_snr_head.
+// x: the 16 raw samples of a window wholly past the head rows (anywhere: global memory or LDS)
+__device__ __forceinline__ double window_snr16_from(const DecView& v, const cplx* xin) {
+    cplx x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = xin[i];
+    fft16(x);
+    x[0].x -= 16.0 * v.cr; x[0].y -= 16.0 * v.ci;
+    double P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }   // abs(fft(.)).^2
+    return snr_from_power<16>(P);
+}
 __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     cplx x[16];
 #pragma unroll
@@ -158,6 +170,10 @@ struct CoarseArgs {
     int mv_len, fft_len; double th;           // modes 1/2 (mode 0 derives them like the reference)
     long t_lo, t_hi; double avg_snr;          // mode 2: target_set and fixed average
     double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
+    long snr_nwin;                            // windows per stream in that table: 0 = those of the moving search only (the first
+                                              // 23 frames); len-fft_len+1 = every window of the stream, and the hop walk reads it
+    double snr_screen_db;                     // ... where entries past the moving search may read -inf: "proven below this level"
+    int snr_tile;                             // ... and k_coarse_snr's workgroup j handles later windows [j, j+1) * snr_tile (<= CS_TILE, multiple of 4)
     int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
     double csum_all;                          // mean_corr: the input is the FIR of the raw bytes; remove mean*csum on load
     const double* csum_head; int n_head;      //            partial tap sums of the rows that overlap filter()'s zero initial state
@@ -229,28 +245,143 @@ __device__ __forceinline__ void coarse_twiddles(cplx* tw, int fft_len, int tid, 
 // grid (ceil(nwin/256), S), block 256.  FFT16: the reference geometry (16-point windows, radix-2 in registers); the
 // other instance serves any window length 2..64 by direct DFTs (a called function: keeping it out of the FFT16
 // instance keeps that one free of scratch memory and within 128 registers -- four blocks per CU).
-template <bool FFT16>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_coarse_snr(CoarseArgs a) {
+#define CS_TILE 1024          /* k_coarse_snr<.,true>: most windows past the moving search one workgroup screens */
+#define CS_SNR_THREADS 256
+// Screening level test of one window for k_coarse_snr (see there): |r1|^2 < g(rho_X)^2 r0^2 proves SNR < X dB.
+// Four consecutive windows per call (b .. b+3 of the staged tile xt), the lag products sliding from one to the next;
+// bit k of the result: window b+k has to be computed in full.
+__device__ __forceinline__ unsigned screen4(const cplx* xt, int b, double cr, double ci, double gx2) {
+    cplx xp = xt[b];
+    xp.x -= cr; xp.y -= ci;
+    double rr = 0.0, ri = 0.0, e = xp.x * xp.x + xp.y * xp.y;
+    cplx xo[4];                                          // x'[b..b+3]: the samples that leave
+    double pr[3], pi_[3];                                // p[b..b+2]:  the lag products that leave
+    xo[0] = xp;
+#pragma unroll
+    for (int n = 1; n <= 3; ++n) {
+        cplx xn = xt[b + n];
+        xn.x -= cr; xn.y -= ci;
+        const double qr = xn.x * xp.x + xn.y * xp.y, qi = xn.y * xp.x - xn.x * xp.y;   // x'[n] conj(x'[n-1])
+        pr[n - 1] = qr; pi_[n - 1] = qi; xo[n] = xn;
+        rr += qr; ri += qi;
+        e += xn.x * xn.x + xn.y * xn.y;
+        xp = xn;
+    }
+#pragma unroll 4
+    for (int n = 4; n < 16; ++n) {
+        cplx xn = xt[b + n];
+        xn.x -= cr; xn.y -= ci;
+        rr += xn.x * xp.x + xn.y * xp.y; ri += xn.y * xp.x - xn.x * xp.y;
+        e += xn.x * xn.x + xn.y * xn.y;
+        xp = xn;
+    }
+    cplx x_last = xp, x_lo = xo[0];                      // x'[b+15], x'[b]
+    unsigned need = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k > 0) {                                     // slide by one: sample b+k-1 leaves, b+k+15 enters
+            cplx xn = xt[b + k + 15];
+            xn.x -= cr; xn.y -= ci;
+            rr += xn.x * x_last.x + xn.y * x_last.y - pr[k - 1];
+            ri += xn.y * x_last.x - xn.x * x_last.y - pi_[k - 1];
+            e += xn.x * xn.x + xn.y * xn.y - (xo[k - 1].x * xo[k - 1].x + xo[k - 1].y * xo[k - 1].y);
+            x_last = xn;
+            x_lo = xo[k];
+        }
+        // + the wrap term x'[first] conj(x'[last]) of the circular lag
+        const double r1r = rr + (x_lo.x * x_last.x + x_lo.y * x_last.y), r1i = ri + (x_lo.y * x_last.x - x_lo.x * x_last.y);
+        if (!(r1r * r1r + r1i * r1i < gx2 * (e * e))) need |= 1u << k;     // (NaN: computed in full)
+    }
+    return need;
+}
+
+// k_coarse_snr: the per-window SNRs (move_fft_snr_runtime_avg.m:17-27) of the moving search, one window per thread.
+// grid (blocks, S).  SCREEN (latency path, 16-point windows): the table also covers every later window of the stream so
+// that the hop walk of k_coarse_scan is a table look-up; block j does windows [256 j, 256 j + 256) of the moving search
+// in full AND the j-th tile of a.snr_tile later windows, of which all but a few percent are ruled out without a spectrum:
+//   With P_k the window's 16 powers (DC removed), S its strongest bin with both neighbours and rho = S / (sum - S) the
+//   quantity whose 10 log10 is the SNR, the circular lag-1 autocorrelation r1 = sum_n x[(n+1) mod 16] conj(x[n]) =
+//   (1/16) sum_k P_k e^(2 pi i k/16) satisfies |r1| >= Re(r1 e^(-2 pi i m/16)) >= (1/16) [S cos(2 pi/16) - (sum - S)]
+//   (m the strongest bin), and r0 = sum_n |x[n]|^2 = (1/16) sum_k P_k; so |r1| / r0 >= (cos(pi/8) rho - 1) / (rho + 1) =: g(rho),
+//   increasing in rho.  A window with |r1| < g(rho_X) r0 therefore has SNR < X dB = a.snr_screen_db: it gets -inf ("below X")
+//   and no FFT.  The hop walk only asks "snr - hit_avg_snr > th" and uses the table only when hit_avg_snr + th > X.
+// The survivors are compacted and computed in full after the moving search's windows.
+template <bool FFT16, bool SCREEN = false>
+__global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_coarse_snr(CoarseArgs a) {
     __shared__ cplx tw[64];
     const CoarseGeom g = coarse_geom(a);
     if (g.fft_len > 64 || g.fft_len < 2 || g.n_first > a.len) return;   // the scan kernel reports the index error
-    if (!FFT16) coarse_twiddles(tw, g.fft_len, threadIdx.x, 256);
+    const int tid = threadIdx.x;
+    if (!FFT16) coarse_twiddles(tw, g.fft_len, tid, 256);
     __syncthreads();
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= g.nwin) return;
+    const long i = (long)blockIdx.x * 256 + tid;
     double mr = 0.0, mi = 0.0;
-    if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }
+    if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }   // (whole block: wave 0 adds, barrier)
     const DecView s = dec_view(a, blockIdx.y, mr, mi);
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    const double r = FFT16 ? window_snr16(s, i) : window_snr_generic(s, i, g.fft_len, tw);
-    a.snr_g[(size_t)blockIdx.y * a.snr_stride + i] = r;
+    double* tab = a.snr_g + (size_t)blockIdx.y * a.snr_stride;
+    if (FFT16) {
+        // the block's 256 windows overlap in all but one sample each: stage the 271 samples they cover in LDS once
+        // instead of 16 loads per window through the vector cache
+        __shared__ cplx xw[256 + 16];
+        __shared__ cplx xt[SCREEN ? CS_TILE + 20 : 1];
+        __shared__ unsigned short list[SCREEN ? CS_TILE : 1];
+        __shared__ int sh_cnt;
+        const int nthr = SCREEN ? CS_SNR_THREADS : 256;
+        const long b0 = (long)blockIdx.x * 256;
+        for (int j = tid; j < 256 + 15; j += nthr) xw[j] = b0 + j < a.len ? s.s[b0 + j] : make_double2(0.0, 0.0);
+        int nw = 0;
+        long w0 = 0;
+        if (SCREEN) {
+            w0 = g.nwin + (long)blockIdx.x * a.snr_tile;
+            const long left = a.snr_nwin - w0;
+            nw = left <= 0 ? 0 : (left < a.snr_tile ? (int)left : a.snr_tile);
+            for (int j = tid; j < nw + 15; j += nthr) xt[j] = s.s[w0 + j];
+            if (tid == 0) sh_cnt = 0;
+        }
+        __syncthreads();
+        if (SCREEN && nw > 0) {
+            const double rho = exp10(a.snr_screen_db / 10.0);
+            const double gx = (0.9238795325112867 * rho - 1.0) / (rho + 1.0);
+            const double gx2 = gx > 0.0 ? gx * gx * (1.0 - 1e-9) : 0.0;   // (margin over the ~1e-14 rounding of the sums)
+            for (int b = 4 * tid; b < nw; b += 4 * nthr) {
+                const unsigned need = screen4(xt, b, s.cr, s.ci, gx2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = b + k < nw;
+                    const bool pass = in && ((need >> k) & 1u);
+                    const unsigned long long m = __ballot(pass);
+                    int base = 0;
+                    if ((tid & 63) == 0 && m) base = atomicAdd(&sh_cnt, __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (pass) list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)(b + k);
+                    else if (in) tab[w0 + b + k] = -INFINITY;
+                }
+            }
+        }
+        if (SCREEN) __syncthreads();
+        // FFT passes: the moving search's window of each thread, then the survivors (~45 per tile: the first wave)
+        const int cnt = SCREEN ? sh_cnt : 0;
+        for (int k0 = -256; k0 < cnt; k0 += 256) {
+            const cplx* src = nullptr;
+            int dst = 0;                                 // (a stream's table stays far below 2^31 entries)
+            if (k0 < 0) {
+                if (i < g.nwin) { src = xw + tid; dst = (int)i; }
+            } else if (k0 + tid < cnt) {
+                const int wi = list[k0 + tid];
+                src = xt + wi; dst = (int)w0 + wi;
+            }
+            if (src) tab[dst] = window_snr16_from(s, src);
+        }
+    } else {
+        if (i < g.nwin) tab[i] = window_snr_generic(s, i, g.fft_len, tw);
+    }
     if (FFT16 && blockIdx.x == 0 && s.n_head > 0) {   // (block-uniform) redo the head windows with per-sample DC removal
         __shared__ cplx hx[64 + 8];
         const int nh = s.n_head < 8 ? s.n_head : 8;
-        if (threadIdx.x < nh + g.fft_len - 1 && threadIdx.x < g.n_first) hx[threadIdx.x] = dv_load(s, threadIdx.x);
+        if (tid < nh + g.fft_len - 1 && tid < g.n_first) hx[tid] = dv_load(s, tid);
         __syncthreads();
-        if (threadIdx.x < nh && threadIdx.x < g.nwin)
-            a.snr_g[(size_t)blockIdx.y * a.snr_stride + threadIdx.x] = window_snr16_head(hx + threadIdx.x);
+        if (tid < nh && tid < g.nwin) tab[tid] = window_snr16_head(hx + tid);
     }
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
@@ -494,6 +625,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (a.mode == 0) {
             if (hit == 0x7fffffff) {
                 if (tid == 0) set_status(st, 3, GSMCAL_S_NO_FCCH);
+            } else if (FFT16 && a.snr_nwin >= len - (fft_len - 1) &&
+                       st->hit_avg_snr + th > a.snr_screen_db + 1e-6 + (exact ? 0.0 : cert_delta)) {
+                // ---- hop loop of FCCH_coarse_position.m:32-86 on the SNR table of the whole stream (k_coarse_snr computed every
+                // window, not only those of the moving search): specific_fft_snr_fix_avg.m:10-25 is then 11 table entries and
+                // a ballot.  One wave; lanes 0..10 hold the +10-frame candidates, lanes 16..26 the +11-frame ones of the same
+                // hop, fetched together.  With a certified average (1) a decision inside cert_delta repeats the stream with
+                // the exact replay, as in the moving search.
+                __shared__ int sh_n;
+                if (tid < 64) {
+                    const int lane = tid;
+                    const double* tab = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
+                    const double hit_avg_snr = st->hit_avg_snr;
+                    const int dec = a.decimation_ratio;
+                    const long d0 = (long)round(12500.0 / (double)dec);     // :35 round() half away from zero
+                    const long d1 = (long)round(13750.0 / (double)dec);     // :36
+                    const int max_offset = 5, nt = 2 * max_offset + 1;
+                    const long limit = (len - (fft_len - 1)) - max_offset;
+                    const unsigned gmask = (1u << nt) - 1u;
+                    long cur = hit + 1;
+                    int nn = 1;
+                    bool redo = false;
+                    if (lane == 0) {
+                        st->coarse_pos[0] = (double)((cur - 1) * dec + 1);  // :91
+                        st->coarse_snr[0] = st->mv_hit_snr;
+                    }
+                    const int grp = lane >> 4, ci = lane & 15;
+                    while (nn < MAXH) {
+                        const long nx0 = cur + d0, nx1 = cur + d1;
+                        if (nx0 > limit) break;                              // :49
+                        const bool g1ok = nx1 <= limit;                      // :67
+                        const bool cand = ci < nt && (grp == 0 || (grp == 1 && g1ok));
+                        const long w = (grp ? nx1 : nx0) - max_offset + ci;  // 1-based window
+                        const double v = cand ? tab[w - 1] : -INFINITY;
+                        const bool is_hit = cand && (v - hit_avg_snr > th);  // NaN compares false
+                        const bool is_unc = !exact && cand && !(fabs((v - hit_avg_snr) - th) > cert_delta);
+                        const unsigned long long hb = __ballot(is_hit), ub = __ballot(is_unc);
+                        const unsigned h0 = (unsigned)hb & gmask, u0 = (unsigned)ub & gmask;
+                        const unsigned h1 = (unsigned)(hb >> 16) & gmask, u1 = (unsigned)(ub >> 16) & gmask;
+                        // every candidate the reference looks at (up to the first hit, else all of the group) must be decided for good
+                        if (u0 & (h0 ? (2u << (__ffs(h0) - 1)) - 1u : gmask)) { redo = true; break; }
+                        int src;
+                        long ncur;
+                        if (h0) {
+                            src = __ffs(h0) - 1;
+                            ncur = nx0 - max_offset + src;
+                        } else if (g1ok) {                                   // :65 try across the idle frame
+                            if (u1 & (h1 ? (2u << (__ffs(h1) - 1)) - 1u : gmask)) { redo = true; break; }
+                            if (!h1) break;                                  // both miss
+                            src = __ffs(h1) - 1;
+                            ncur = nx1 - max_offset + src;
+                            src += 16;
+                        } else break;                                        // :67
+                        if (lane == src) {
+                            st->coarse_pos[nn] = (double)((ncur - 1) * dec + 1);
+                            st->coarse_snr[nn] = v;
+                        }
+                        cur = ncur;
+                        ++nn;
+                    }
+                    if (lane == 0) {
+                        sh_n = nn;
+                        if (redo) sh_redo = 1;
+                        st->n_coarse = nn;
+                    }
+                }
+                __syncthreads();
+                n = sh_n;
             } else {
                 // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units), whole block ----
                 __shared__ long sh_cur;
