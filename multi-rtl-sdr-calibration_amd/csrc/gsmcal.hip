@@ -586,11 +586,12 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     const long nwin = n_first - (fft_len - 1);
     const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
-    // latency path (few streams, one workgroup per CU at most): k_coarse_snr fills in every window of the stream and the hop
-    // walk of k_coarse_scan becomes table look-ups; big batches keep the table to the moving search's windows
+    // latency path (few streams: one wave of k_coarse_snr workgroups still fits the chip): k_coarse_snr fills in every window of
+    // the stream and the hop walk of k_coarse_scan becomes table look-ups; bigger batches keep the table to the moving
+    // search's windows (at 200 captures the longer table kernel already costs what the shorter walk saves)
     long ntab = nwin;
     unsigned sblocks = (unsigned)((nwin + 255) / 256);
-    if (fft_len == 16 && S <= c->n_cu && c->snr_full && len - (fft_len - 1) > nwin) {
+    if (fft_len == 16 && 2 * S <= c->n_cu && c->snr_full && len - (fft_len - 1) > nwin) {
         ntab = len - (fft_len - 1);
         a.snr_nwin = ntab;
         a.snr_screen_db = c->snr_screen_db;
