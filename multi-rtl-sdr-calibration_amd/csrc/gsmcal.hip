@@ -54,6 +54,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
+    int win_l0_len = 0, win_l0_H = 0;  // > 0: `win` holds the fine search's level-0 windows (this length each, H per stream) of the call in progress
 };
 
 struct gsmcal_ctx {
@@ -82,6 +83,7 @@ struct gsmcal_ctx {
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
+    bool reuse_l0 = true;           // GSMCAL_REUSE_L0=0: every per-burst gather filters its raw bytes again
     bool snr_full = true;           // GSMCAL_SNR_FULL=0: the hop walk of FCCH_coarse_position computes its own 16-point spectra
     double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
@@ -354,6 +356,9 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         }
     }
     if (!fg.raw) RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
+    // from here on the lane's window buffer holds level 0 of every fine window (nothing later in a batch call writes it)
+    c->cur->win_l0_len = (src.kind == SRC_RAW && lvl == 0 && c->reuse_l0) ? g.fine_wlen : 0;
+    c->cur->win_l0_H = H;
     StepArgs sa_fine = sa;
     if (c->prescreen) {
         // certificate (exact, tone bins) -> packed-fp32 sweep of the chunks it left open -> exact fp64 on what survives
@@ -402,7 +407,8 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     // bursts of the resampled (not yet derotated) stream: level lvl+1 -- gather, spectrum argmax, tone estimate
     // and SNR gate fused per burst
     {
-        const GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
+        GatherArgs ga = gather_args(src, lvl + 1, g.nfft);
+        if (c->cur->win_l0_len > 0) { ga.l0 = win; ga.l0_stream_stride = sstride; ga.l0_win_stride = wstride; ga.l0_len = c->cur->win_l0_len; }
         TailArgs tl;   // FCCH_fine_correction's carrier decision (+ the SCH stage's window setup) rides on the last burst
         RET_IF(make_tail(c, S, sa, next_sch_lvl >= 0 ? (STEP_CARRIER_DECIDE | STEP_SCH_SETUP) : STEP_CARRIER_DECIDE, lvl,
                          next_sch_lvl >= 0 ? next_sch_lvl : 0, tl));
@@ -451,7 +457,10 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     {
-        const GatherArgs ga = gather_args(src, lvl, g.nfft);
+        GatherArgs ga = gather_args(src, lvl, g.nfft);
+        if (c->cur->win_l0_len == g.fine_wlen && c->cur->win_l0_H == H && src.kind == SRC_RAW) {
+            ga.l0 = win; ga.l0_stream_stride = sstride; ga.l0_win_stride = wstride; ga.l0_len = c->cur->win_l0_len;
+        }
         TailArgs tl;   // carrier_correct_post_SCH's decision (+ the calibration table row) rides on the last burst
         RET_IF(make_tail(c, S, sa, table ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, lvl, 0, tl));
         LAUNCH(c, k_burst_tone<0>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
@@ -844,6 +853,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (ce) c->certify = atoi(ce) != 0;
     const char* sfe = getenv("GSMCAL_SNR_FULL");
     if (sfe) c->snr_full = atoi(sfe) != 0;
+    const char* rle = getenv("GSMCAL_REUSE_L0");
+    if (rle) c->reuse_l0 = atoi(rle) != 0;
     const char* sse = getenv("GSMCAL_SNR_SCREEN_DB");
     if (sse) c->snr_screen_db = atof(sse);
     const char* fge = getenv("GSMCAL_FUSE_GATHER");

@@ -1534,6 +1534,8 @@ __device__ __forceinline__ float fc_group8_sum(float v) {     // sum over the 8 
 }
 
 __host__ __device__ inline int fc_gcd64(int n) { int b = 64; while (n % b) b >>= 1; return b; }
+// threads of k_fine_cert: 8 per chunk, at least 256.  (320 would save the nearly empty third round of the level-1 phase --
+// 69 blocks handed out 32 at a time -- but five-wave workgroups no longer sit three to a CU: measured 77 us against 59.)
 __host__ inline int fc_threads(int nshift) {
     const int n = ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64;
     return n < 256 ? 256 : n;

@@ -284,8 +284,14 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
     for (int i = tid; i < len_ts; i += 512) tc[i] = make_double2(ts[i].x, -ts[i].y);
     __syncthreads();
     const int seg = (len_ts + SCH_PARTS - 1) / SCH_PARTS;
-    for (int t = tid; t < nshift * SCH_PARTS; t += 512) {
-        const int o = t % nshift, q = t / nshift;   // consecutive lanes: consecutive offsets (conflict-free reads)
+    // (shift, part) tasks, one per thread and round.  When whole rounds leave one or two shifts over (8x oversampling:
+    // 129 shifts x 4 parts = one round of 512 + 4 tasks), those are not given a nearly empty round of their own: the whole
+    // block forms each of their sums together.
+    const int full = (nshift * SCH_PARTS / 512) * (512 / SCH_PARTS);          // shifts covered by whole rounds
+    const int n_task_sh = (full > 0 && nshift - full <= 2) ? full : nshift;
+    __shared__ double rest[2][2 * 8];
+    for (int t = tid; t < n_task_sh * SCH_PARTS; t += 512) {
+        const int o = t % n_task_sh, q = t / n_task_sh;   // consecutive lanes: consecutive offsets (conflict-free reads)
         const int n0 = q * seg, n1 = n0 + seg < len_ts ? n0 + seg : len_ts;
         double ar = 0.0, ai = 0.0;
 #pragma unroll 8
@@ -296,10 +302,25 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
         }
         part[q * nshift + o] = make_double2(ar, ai);
     }
+    for (int o = n_task_sh; o < nshift; ++o) {            // (block-uniform) a left-over shift: 512 products at a time, per-wave sums
+        double ar = 0.0, ai = 0.0;
+        for (int n = tid; n < len_ts; n += 512) {
+            const cplx c = tc[n], v = xs[o + n];
+            ar = fma(c.x, v.x, fma(-c.y, v.y, ar));
+            ai = fma(c.x, v.y, fma(c.y, v.x, ai));
+        }
+        ar = wave_sum(ar);
+        ai = wave_sum(ai);
+        if ((tid & 63) == 0) { rest[o - n_task_sh][2 * (tid >> 6)] = ar; rest[o - n_task_sh][2 * (tid >> 6) + 1] = ai; }
+    }
     __syncthreads();
     for (int o = tid; o < nshift; o += 512) {
         double ar = 0.0, ai = 0.0;
-        for (int q = 0; q < SCH_PARTS; ++q) { ar += part[q * nshift + o].x; ai += part[q * nshift + o].y; }
+        if (o < n_task_sh) {
+            for (int q = 0; q < SCH_PARTS; ++q) { ar += part[q * nshift + o].x; ai += part[q * nshift + o].y; }
+        } else {
+            for (int q = 0; q < 8; ++q) { ar += rest[o - n_task_sh][2 * q]; ai += rest[o - n_task_sh][2 * q + 1]; }
+        }
         const double m = hypot(ar, ai);
         cv[o] = m * m;                      // :53 abs(...).^2
     }
@@ -340,7 +361,7 @@ __device__ __forceinline__ unsigned long long bits_below(int n) { return n >= 64
 __device__ __forceinline__ void fine_sentinel(StreamState* st) {
     st->n_fcch = 0; st->fcch_is_sentinel = 1;
     st->sampling_ppm1 = INFINITY; st->carrier_ppm1 = INFINITY;
-    st->r1_kind = 0; st->n_win = 0; st->n_fine = 0;
+    st->r1_kind = 0; st->n_win = 0; st->n_fine = 0; st->n_fine_ws = 0;
 }
 
 // FCCH_fine_correction.m:8-46 -- window list for the fine search (level `lvl`)
@@ -360,8 +381,8 @@ __device__ void d_fine_setup(StreamState* st, int ov, int lvl, int min_hits, int
     const unsigned long long m_brk = __ballot(brk), m_bad = __ballot(in && sp < 1);
     const int cnt = m_brk ? __ffsll((long long)m_brk) - 1 : nc;
     if (m_bad & bits_below(cnt)) { LANE0(set_status(st, 0, GSMCAL_E_INDEX)); return; }   // (n_win stays 0)
-    if (lane < cnt) st->win_start[lane] = sp - 1;
-    LANE0(st->n_win = cnt);
+    if (lane < cnt) { st->win_start[lane] = sp - 1; st->fine_ws[lane] = sp - 1; }
+    LANE0(st->n_win = cnt; st->n_fine_ws = lvl == 0 ? cnt : 0);
 }
 
 // the reference's spacing test of consecutive positions (FCCH_fine_correction.m:85-93, SCH_corr_rate_correction.m:96-104):

@@ -580,6 +580,9 @@ struct GatherArgs {
     const cplx* arr;    long arr_stride;     // elements per stream
     const double* coef;
     cplx* dst; long dst_stream_stride, dst_win_stride;
+    // raw sources: level-0 samples the fine search already filtered (window h of stream s covers level-0 indices
+    // [st.fine_ws[h], st.fine_ws[h] + l0_len) at l0 + s*l0_stream_stride + h*l0_win_stride); nullptr: none
+    const cplx* l0; long l0_stream_stride, l0_win_stride; int l0_len, pad2;
 };
 
 __device__ __forceinline__ long level_len(const StreamState* st, int level) {
@@ -644,7 +647,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     // to the others through LDS: NT/64 waves stepping through the same serial code only compete for the issue slots.
     __shared__ long pl_lo[NLEVELS], pl_hi[NLEVELS], pl_n0, pl_start;
     __shared__ double pl_param[NLEVELS], pl_mr, pl_mi;
-    __shared__ int pl_type[NLEVELS], pl_L;
+    __shared__ int pl_type[NLEVELS], pl_L, pl_l0h;
+    __shared__ long pl_l0off;
     // ... which meanwhile fetch the filter taps
     if (a.src_kind != SRC_ARR && NT > 64 && tid >= 64)
         for (int i = tid - 64; i < a.ntaps; i += NT - 64) c_s[i] = a.coef[i];
@@ -687,7 +691,20 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
                 }
             }
         }
+        // a window the fine search has filtered already and that holds all of [clo, chi]
+        int l0h = -1;
+        long l0off = 0;
+        if (a.l0 && a.src_kind == SRC_RAW && L > 0) {
+            const int nf = st->n_fine_ws;
+            const long fw = (tid < nf && tid < MAXH) ? st->fine_ws[tid] : 0;
+            const unsigned long long m = __ballot(tid < nf && tid < MAXH && fw <= clo && chi < fw + a.l0_len);
+            if (m) {
+                l0h = __ffsll((long long)m) - 1;
+                l0off = clo - __shfl(fw, l0h, 64);
+            }
+        }
         if (tid == 0) {
+            pl_l0h = l0h; pl_l0off = l0off;
             pl_lo[0] = clo; pl_hi[0] = chi;
             pl_n0 = pre_n0; pl_start = start; pl_L = (int)L; pl_mr = pre_mr; pl_mi = pre_mi;
 #pragma unroll
@@ -715,6 +732,10 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             const long g = lo0 + i;
             out0[i] = (g >= 0 && g < n0) ? x[g] : make_double2(0.0, 0.0);
         }
+    } else if (pl_l0h >= 0) {
+        // the same filter outputs (same taps, same order of additions) are in the fine search's window buffer
+        const cplx* x = a.l0 + (size_t)s * a.l0_stream_stride + (size_t)pl_l0h * a.l0_win_stride + pl_l0off;
+        for (int i = tid; i < cnt0; i += NT) out0[i] = x[i];
     } else {
         const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
         const long n0 = pre_n0;

@@ -62,6 +62,8 @@ struct alignas(16) StreamState {
     int n_win;
     long win_start[MAXH];    // 0-based start index at the window's level
     // ---- fine search ----
+    int n_fine_ws;           // windows of the fine search and where they start at level 0: their filtered samples stay in the
+    long fine_ws[MAXH];      // lane's window buffer, and later per-burst gathers inside one of them read level 0 from there
     int n_fine;              // last_idx
     double fine_first[MAXH]; // first-round FCCH_pos (8x units, 1-based)
     int n_fcch;              // length(FCCH_pos) returned
