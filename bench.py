@@ -64,7 +64,11 @@ def parse():
 class Calib:
     """D streams resident in HBM + everything one calibration step needs."""
 
-    def __init__(self, torch, gsmcal, dev, ctx, raw_t, N, mode, coef, ts, fc):
+    def __init__(self, torch, gsmcal, dev, ctx, raw_t, N, mode, coef, ts, fc, zero_copy=True):
+        # zero_copy: the library's last kernel stores the table straight into pinned host memory (the C ABI takes any
+        # device-accessible pointer for its outputs), so the step ends with the table on the host and no copy is queued;
+        # off for the RCCL path, whose all-gather reads the table from device memory
+        self.zero_copy = zero_copy
         self.torch, self.g, self.dev, self.ctx = torch, gsmcal, dev, ctx
         self.raw_t, self.N, self.D = raw_t, N, raw_t.shape[0]
         self.coef, self.ts = coef, ts
@@ -84,14 +88,21 @@ class Calib:
         cp, tp, fp = self._p
         rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(self.raw_t.data_ptr()), self.D if d is None else d, self.N,
                                             cp, len(self.coef), tp, len(self.ts), fp,
-                                            C.c_void_p(self.table_t[b].data_ptr()), C.c_void_p(self.pos_t.data_ptr()),
+                                            C.c_void_p((self.host_table[b] if self.zero_copy else self.table_t[b]).data_ptr()),
+                                            C.c_void_p(self.pos_t.data_ptr()),
                                             C.c_void_p(self.r_t.data_ptr()) if self.r_t is not None else None,
                                             C.c_void_p(self.rlen_t.data_ptr()))
         ctx.check(rc, "gsmcal_calibrate_batch_dev")
 
     def to_host(self, b=0):
-        """the step ends with the table on the host: asynchronous copy on the same stream (pinned destination)"""
-        self.host_table[b].copy_(self.table_t[b], non_blocking=True)
+        """the step ends with the table on the host: already there (zero_copy), else an asynchronous copy on the same
+        stream into the pinned destination"""
+        if not self.zero_copy:
+            self.host_table[b].copy_(self.table_t[b], non_blocking=True)
+
+    def table(self, b=0):
+        """the table of buffer b as a host tensor (after a synchronize)"""
+        return self.host_table[b] if self.zero_copy else self.table_t[b].cpu()
 
 
 def time_steps(torch, dev, fn, steps, warmup, fence=None):
@@ -180,7 +191,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
-    cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc)
+    cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc, zero_copy=not use_dist)
 
     # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
     # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written, and the only wait is
@@ -216,7 +227,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     last = ((nstep[0] - 1) & 1) if use_dist else 0
-    table = (cal.host_table[last] if not use_dist else cal.table_t[last].cpu()).numpy().copy()
+    table = cal.table(last).numpy().copy()
 
     # ---- every rank checks rows of its OWN shard against the CPU oracle before anything is reported ----
     from oracle import gsmcal_oracle as oracle
@@ -378,7 +389,8 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream):
         sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
                               "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
                               "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4)}
-        assert torch.equal(cs.table_t[0], cal.table_t[0]) or bool(torch.allclose(cs.table_t[0], cal.table_t[0], equal_nan=True))
+        torch.cuda.synchronize(dev)
+        assert torch.equal(cs.table(0), cal.table(0)) or bool(torch.allclose(cs.table(0), cal.table(0), equal_nan=True))
         del cs
         torch.cuda.empty_cache()
     # scanner path: BASELINE config 3 (200 captures) and config 5 per GPU (12 800 captures, 16.4 GB, generated on the device)
@@ -421,7 +433,8 @@ def bench_two_in_flight(args, torch, gsmcal, dev, cal, coef, ts, fc, N):
             cals[i].to_host(0)
     try:
         t = time_steps(torch, dev, step, 2 * args.steps, 4) / (2 * args.steps)
-        ok = bool(torch.equal(cals[0].table_t[0], cal.table_t[0]) or torch.allclose(cals[0].table_t[0], cal.table_t[0], equal_nan=True))
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(cals[0].table(0), cal.table(0)) or torch.allclose(cals[0].table(0), cal.table(0), equal_nan=True))
     finally:
         for c in ctxs:
             c.close()
@@ -490,12 +503,15 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
     gathered = torch.zeros((world * D, 2), dtype=torch.float64, device=dev) if use_dist else None
     cp = coef.ctypes.data_as(gsmcal._lib.c_double_p)
 
+    # single rank: the acceptance kernel stores (snr, num_hit) straight into pinned host memory (no copy queued)
+    dst_t = out_t if use_dist else host_out
+
     def step():
         ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
-                                                     C.c_void_p(out_t.data_ptr()), None, None, None), "scan")
+                                                     C.c_void_p(dst_t.data_ptr()), None, None, None), "scan")
         if use_dist:
             dist.all_gather_into_tensor(gathered, out_t)
-        host_out.copy_(out_t, non_blocking=True)
+            host_out.copy_(out_t, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -232,6 +232,9 @@ int gsmcal_calibrate_batch(gsmcal_ctx* ctx, const uint8_t* raw, int d, long n, c
                            int ntaps, const double* sch_training_sequence, int len_ts,
                            const double* carrier_freq, double* table, double* pos_info,
                            double* r_correct, long* r_len);
+/* The d_* outputs of the *_dev entry points may be any memory the GPU can store to, in particular pinned host memory
+ * (hipHostMalloc): the kernels that finish a batch then write the table / (snr, num_hit) rows where the host reads them
+ * after synchronising the stream, and no device-to-host copy has to be queued behind the batch (bench.py does this). */
 int gsmcal_calibrate_batch_dev(gsmcal_ctx* ctx, const uint8_t* d_raw, int d, long n, const double* coef,
                                int ntaps, const double* sch_training_sequence, int len_ts,
                                const double* carrier_freq, double* d_table, double* d_pos_info,
