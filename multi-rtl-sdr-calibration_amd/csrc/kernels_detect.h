@@ -486,12 +486,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         uint4* dst = (uint4*)st;
         for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += 256) dst[i] = src[i];
     }
-    if (fft_len >= 2 && fft_len <= 64)
-        for (int i = tid; i < fft_len; i += 256) {
-            double sn, cs;
-            sincospi(-2.0 * (double)i / (double)fft_len, &sn, &cs);
-            tw[i] = make_double2(cs, sn);
-        }
+    // twiddles of the window DFTs: the batch path with the full SNR table needs them only if its hop walk falls back to
+    // its own spectra (built there); sincospi on the way to the first barrier costs the whole block ~1 us
+    const bool tw_lazy = FFT16 && a.mode == 0 && a.snr_nwin > 0;
+    auto make_tw = [&]() {
+        if (fft_len >= 2 && fft_len <= 64)
+            for (int i = tid; i < fft_len; i += 256) {
+                double sn, cs;
+                sincospi(-2.0 * (double)i / (double)fft_len, &sn, &cs);
+                tw[i] = make_double2(cs, sn);
+            }
+    };
+    if (!tw_lazy) make_tw();
     __syncthreads();
     const bool want_cert = !bad && a.mode == 0;
     if (tid == 0) {
@@ -526,8 +532,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         const int p0 = tid * sc_per;
         double loc = 0.0;
         for (int i = 0; i < sc_per; ++i) loc += (p0 + i < sc_total) ? snr_s[p0 + i] : 0.0;
-        double inc = loc;
-        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+        const double inc = wave_scan_incl(loc);
         if (lane == 63) sh_ws[wave] = inc;
         __syncthreads();
         double base = 0.0;
@@ -552,14 +557,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         }
         __syncthreads();
         if (tid < 64) {
-            // the average the decided hit sees (64 lanes + a shuffle tree: within the same bound)
+            // the average the decided hit sees (64 lanes + a reduction tree: within the same bound)
             const int pred = sh_pred;
             const bool ok = !(sh_unc < pred);
             double sm = 0.0;
             if (ok && pred != 0x7fffffff) {
                 for (int q = tid; q < mv_len; q += 64) sm += snr_s[pred + q];
-                for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
             }
+            sm = wave_sum(sm);
             if (tid == 0) {
                 if (!ok) sh_exact = 1;
                 else if (pred != 0x7fffffff) { sh_hit = pred; sh_avg = sm / (double)mv_len; }
@@ -694,6 +699,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                 n = sh_n;
             } else {
                 // ---- hop loop of FCCH_coarse_position.m:32-86 (positions 1-based, decimated units), whole block ----
+                if (tw_lazy) make_tw();                                  // (block-uniform; the barrier below the set-up covers it)
                 __shared__ long sh_cur;
                 __shared__ int sh_stop, sh_need1, sh_took1;
                 const int lane = tid & 63;

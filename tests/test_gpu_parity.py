@@ -650,3 +650,34 @@ def test_params_pod_changes_decisions_and_rejects_geometry(g, setup):
         assert c2.get_params().fine_max_offset == 64
     finally:
         c2.close()
+
+
+def test_outputs_in_pinned_host_memory(g, ctx, setup):
+    """include/gsmcal.h: the d_* outputs of the *_dev entry points may be pinned host memory -- the kernels that finish
+    the batch store the rows there, no copy is queued.  Same table and (snr, num_hit) as through device buffers."""
+    import ctypes as C
+    import torch
+    dp = g._lib.c_double_p
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in (90, 91, 92)])
+    D, N = raw.shape[0], raw.shape[1] // 2
+    raw_t = torch.from_numpy(raw).cuda()
+    coef, ts, cf = setup["coef"], setup["ts"], np.full(D, FC)
+    ref = g.calibrate_batch(raw, coef, ts, FC, ctx=ctx)
+    for _ in range(3):                       # the repeated call replays a graph: the host pointer is part of it
+        host = torch.full((D, g.TABLE_COLS), -7.0, dtype=torch.float64).pin_memory()
+        rc = ctx.lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, coef.ctypes.data_as(dp), len(coef),
+                                                ts.ctypes.data_as(dp), len(ts), cf.ctypes.data_as(dp),
+                                                C.c_void_p(host.data_ptr()), None, None, None)
+        ctx.check(rc, "gsmcal_calibrate_batch_dev")
+        ctx.sync()
+        assert np.array_equal(host.numpy(), ref["table"], equal_nan=True)
+    caps = np.stack([g.synth.make_stream(dongle=93, arfcn=i, num_frames=40, bcch=(i != 1))[0] for i in range(3)])
+    sc = g.fcch_scan_batch(caps, setup["coef30"], ctx=ctx)
+    caps_t = torch.from_numpy(caps).cuda()
+    out = torch.full((3, 2), -7.0, dtype=torch.float64).pin_memory()
+    rc = ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(caps_t.data_ptr()), 3, caps.shape[1] // 2,
+                                            setup["coef30"].ctypes.data_as(dp), len(setup["coef30"]),
+                                            C.c_void_p(out.data_ptr()), None, None, None)
+    ctx.check(rc, "gsmcal_fcch_scan_batch_dev")
+    ctx.sync()
+    assert np.array_equal(out.numpy()[:, 0], sc["snr"]) and np.array_equal(out.numpy()[:, 1], sc["num_hit"])
