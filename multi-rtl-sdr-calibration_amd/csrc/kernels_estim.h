@@ -791,7 +791,7 @@ k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft, const cplx* 
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 6);
 }
 
-__global__ void __launch_bounds__(512) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
                                                     const cplx* __restrict__ ts, int len_ts, int nshift, TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     window_sch_body(sts, a, ts, len_ts, nshift, smem);
