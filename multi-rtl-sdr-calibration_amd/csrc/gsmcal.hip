@@ -79,6 +79,7 @@ struct gsmcal_ctx {
     unsigned g_calib_lru = 0;
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
+    bool graph_always = false;      // GSMCAL_GRAPH=2: also single-stream plans (default: only plans that fork onto internal streams)
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
@@ -558,9 +559,10 @@ size_t coarse_scan_lds(long nwin, int mv_len) {
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
-           bool mean_corr = false, long n0 = 0, int front_decim = 64) {
+           bool mean_corr = false, long n0 = 0, int front_decim = 64, const ScanAccept* accept = nullptr) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
+    if (accept) { a.accept = *accept; a.P = dev_params(c); }
     if (mean_corr) {   // input = FIR of the raw bytes (front_fused): DC removed on load
         a.mean_corr = 1;
         a.partial = (const unsigned long long*)c->cur->partial.p;
@@ -708,8 +710,12 @@ int join_lanes(gsmcal_ctx* c, int nl) {
 // replays.  Capture is never attempted where it cannot work -- the legacy NULL stream, or a user stream that is
 // itself being captured (e.g. inside torch.cuda.graph) -- and any capture failure falls back to eager launches.
 template <class F>
-int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vector<uintptr_t>& key, F enqueue) {
-    bool can_graph = c->use_graph && !c->prof && c->stream != nullptr;
+int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vector<uintptr_t>& key, F enqueue, bool multi_stream) {
+    // A plan on one stream (one lane, no pipeline stages) is launched eagerly: nine back-to-back launches ran 1-5 % faster
+    // than replaying them as a graph (consecutive graph launches sit 8.6 us apart on the GPU's timeline; 0.238 vs 0.242 ms at
+    // 64 streams, 0.125 vs 0.129 at 2, 0.101 vs 0.107 for 200 captures).  Plans that fork onto internal streams replay as a
+    // graph: the event choreography costs more launched piecemeal (12 800 captures: 4.06 vs 4.33 ms).  GSMCAL_GRAPH=2: always.
+    bool can_graph = c->use_graph && (multi_stream || c->graph_always) && !c->prof && c->stream != nullptr;
     if (can_graph) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); can_graph = false; }
@@ -865,6 +871,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (fg && atoi(fg) != 0) c->front_generic = true;
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
+    if (ge && atoi(ge) == 2) c->graph_always = true;
     *out = c;
     return 0;
 }
@@ -1395,21 +1402,19 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         }
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
         if (nl > 1) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim));
-        StepArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.P = dev_params(c);
-        sa.snr_numhit = d_snr_numhit + (size_t)2 * lo;
-        sa.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
-        sa.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
-        sa.counts = d_counts ? d_counts + lo : nullptr;
-        LAUNCH(c, k_step<STEP_SCAN_ACCEPT>, dim3(S), dim3(64), 0, (StreamState*)L.state.p, sa, 0, 0);
+        // the acceptance rule (multi_rtl_sdr_gsm_FCCH_scanner.m:168-185) runs at the end of k_coarse_scan, on the state it just built
+        ScanAccept acc;
+        acc.snr_numhit = d_snr_numhit + (size_t)2 * lo;
+        acc.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
+        acc.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
+        acc.counts = d_counts ? d_counts + lo : nullptr;
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc));
         CHECK_LAUNCH(c);
     }
     RET_IF(join_lanes(c, nl));
     return 0;
     };
-    RET_IF(run_maybe_graph(c, c->g_scan, key, enqueue));
+    RET_IF(run_maybe_graph(c, c->g_scan, key, enqueue, plan_lanes(c, d, false) > 1));
     plan_lanes(c, d, false);
     c->cur = &c->lanes[0];
     c->last_S = d;
@@ -1501,7 +1506,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     else if (c->g_calib[1].key == key) slot = 1;
     else slot = 1 - (int)(c->g_calib_lru & 1u);
     c->g_calib_lru = (unsigned)slot;
-    RET_IF(run_maybe_graph(c, c->g_calib[slot], key, enqueue));
+    RET_IF(run_maybe_graph(c, c->g_calib[slot], key, enqueue, plan_lanes(c, d) > 1));
     plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
     c->cur = &c->lanes[0];
     c->last_S = d;

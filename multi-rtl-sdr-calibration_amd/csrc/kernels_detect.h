@@ -163,6 +163,10 @@ __device__ __forceinline__ double window_snr(const DecView& s, long start, int f
     return fft_len == 16 ? window_snr16(s, start) : window_snr_generic(s, start, fft_len, tw);
 }
 
+// scanner path: where k_coarse_scan puts the acceptance rule's outputs (snr_numhit == nullptr: no acceptance step)
+struct ScanAccept {
+    double* snr_numhit; double* positions; double* pos_snr; int* counts;
+};
 struct CoarseArgs {
     const cplx* s; long s_stride; long len;   // decimated streams
     int decimation_ratio;                     // FCCH_coarse_position's 2nd argument
@@ -172,6 +176,7 @@ struct CoarseArgs {
     double* snr_g; long snr_stride;           // per-window SNRs of the moving search (k_coarse_snr -> k_coarse_scan)
     long snr_nwin;                            // windows per stream in that table: 0 = those of the moving search only (the first
                                               // 23 frames); len-fft_len+1 = every window of the stream, and the hop walk reads it
+    ScanAccept accept; DevParams P;           // scanner path: multi_rtl_sdr_gsm_FCCH_scanner.m:168-185 at the end of k_coarse_scan
     double snr_screen_db;                     // ... where entries past the moving search may read -inf: "proven below this level"
     int snr_tile;                             // ... and k_coarse_snr's workgroup j handles later windows [j, j+1) * snr_tile (<= CS_TILE, multiple of 4)
     int fine_setup_ov;                        // > 0: run FCCH_fine_correction's window setup at the end (batch path)
@@ -387,6 +392,8 @@ __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((
 }
 
 __device__ void d_fine_setup(StreamState* st, int ov, int lvl, int min_hits, int lane);   // kernels_estim.h
+__device__ void d_scan_accept(const StreamState* st, int s, double* snr_numhit, double* positions,
+                              double* pos_snr, int* counts, const DevParams& P, int lane);   // kernels_estim.h
 
 // ---- k_coarse_scan: first hit + hop walk of FCCH_coarse_position, one workgroup per stream ----
 // grid S, block 256.  LDS: state copy | 64 twiddles | 4 x 36 hop samples | 2 x 11 x 17 hop powers | snr[mv_len + nwin + 64].
@@ -931,6 +938,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     }
     __syncthreads();
     if (tid < 64 && a.fine_setup_ov > 0) d_fine_setup(st, a.fine_setup_ov, 0, a.min_hits, tid);
+    if (tid < 64 && a.accept.snr_numhit)
+        d_scan_accept(st, blockIdx.x, a.accept.snr_numhit, a.accept.positions, a.accept.pos_snr, a.accept.counts, a.P, tid);
     __syncthreads();
     CS_STAMP(5);
     {
