@@ -1247,6 +1247,7 @@ __global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ double sh_e[FK_THREADS / 64];
     __shared__ float sh_m[FK_THREADS / 64];
     __shared__ int sh_cnt;
+    __shared__ double sh_D;                     // sum of |d_q| over the chunk's steps: how far any bin's amplitude can move
     const int tid = threadIdx.x;
     const int nstep = nshift - 1;
     const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
@@ -1268,13 +1269,17 @@ __global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int i = tid; i < nfft; i += FK_THREADS) e += fabs(xs[i].x) + fabs(xs[i].y);
     if (tid < FS_CHUNK) {
         float2 v = make_float2(0.0f, 0.0f);     // (zero-padded steps only rotate X: |X| unchanged)
+        double dabs = 0.0;
         if (tid < lim) {
             const cplx a1 = xs[tid + nfft], b1 = xs[tid];
             const double dr = a1.x - b1.x, di = a1.y - b1.y;
             v = make_float2((float)dr, (float)di);
-            e += fabs(dr) + fabs(di);
+            dabs = fabs(dr) + fabs(di);         // >= |d|
+            e += dabs;
         }
         d[tid] = v;
+        dabs = wave_sum(dabs);                  // (FS_CHUNK = 64: exactly the first wave)
+        if (tid == 0) sh_D = dabs;
     }
     for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
     if ((tid & 63) == 0) sh_e[tid >> 6] = e;
@@ -1303,6 +1308,15 @@ __global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu
             const v2f wr = {(float)t0w.x, (float)t1w.x}, wi = {(float)-t0w.y, (float)-t1w.y};
             v2f xr = {(float)X0.x, (float)X1.x}, xi = {(float)X0.y, (float)X1.y};
             if (c == 0) best = xr * xr + xi * xi;            // the start window m = 0 rides with chunk 0
+            // |X_k(t+1)| = |X_k(t) + d_t| <= |X_k(t)| + |d_t|: a bin that starts the chunk more than D = sum |d_q| below
+            // sqrt(P*) stays below it on all 64 shifts -- it cannot hold the window's maximum (P* is attained) and is not
+            // swept.  In the edge chunks the certificate leaves open that is every bin but the few around the tone, so
+            // whole waves skip the loop; an unswept bin counts as 0 in the chunk maximum, which only lowers the bars
+            // (thr below, L in k_fine_verify) -- the safe direction.
+            const double D = sh_D * (1.0 + 1e-9);
+            const bool sweep = !(pstar > 0.0) || !((sqrt(X0.x * X0.x + X0.y * X0.y) + D) * (1.0 + 1e-9) < sp) ||
+                               !((sqrt(X1.x * X1.x + X1.y * X1.y) + D) * (1.0 + 1e-9) < sp);
+            if (sweep) {
 #pragma unroll 8
             for (int t = 0; t < FS_CHUNK; ++t) {
                 const float2 dv = d[t];
@@ -1313,6 +1327,7 @@ __global__ void __launch_bounds__(FK_THREADS) __attribute__((amdgpu_waves_per_eu
                 const v2f p = xr * xr + xi * xi;
                 best.x = fmaxf(best.x, p.x);
                 best.y = fmaxf(best.y, p.y);
+            }
             }
             if (k1 == k0) best.y = 0.0f;
             m = fmaxf(m, fmaxf(best.x, best.y));
