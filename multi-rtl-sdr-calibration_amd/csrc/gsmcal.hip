@@ -64,7 +64,8 @@ struct gsmcal_ctx {
     std::string err;
     Lane lanes[MAX_LANES];
     Lane* cur = nullptr;        // lane the helpers below enqueue on
-    int n_lanes_cfg = 2;        // GSMCAL_LANES: upper bound; a lane gets at least 64 streams (measured: 2 lanes help from 128 streams on)
+    int n_lanes_cfg = 4;        // GSMCAL_LANES: upper bound; a lane gets at least 64 streams (measured: 128 streams 325 / 343 Gsample/s with
+                                // 1 / 2 lanes; 256: 377 / 397 / 421 with 1 / 2 / 4; 512: 421 / 424 / 449-457; 8 or 16 lanes no better)
     int n_lanes_used = 1;
     const double* cf_lane = nullptr;   // carrier_freq of the current lane's first stream (batch path)
     hipEvent_t fork = nullptr;
