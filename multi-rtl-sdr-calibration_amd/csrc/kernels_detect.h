@@ -1695,8 +1695,8 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                 int t = 0;
                 for (; t + 4 <= ntp; t += 4) {        // gather_core's loop: every accumulator takes its taps oldest first
                     const cplx* nx = xq + xs_pad(i0 + t + 4);
+                    const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
                     const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
-                    const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];
                     GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
                     GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
                     GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
