@@ -1460,6 +1460,10 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     __syncthreads();
     const bool slow = n_over > 0 || n_items > FV_MAX_ITEMS;   // block-uniform; pathological inputs only (e.g. all zeros)
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 3);
+    if (n_items == 0 && !slow && fc.p > 0.0) {            // (block-uniform) nothing reaches the bar: the certificate's answer stands
+        if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; peak_store(&out[(size_t)s * H + w], o2); }
+        return;
+    }
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
     double best = -1.0;
     int bt = 0x7fffffff, bk = 0x7fffffff;
