@@ -47,7 +47,7 @@ def parse():
                     help="weak: --streams per GPU (64/GPU: the driver's curve); strong: BASELINE config 4 as stated -- "
                          "--streams in total, sharded block-contiguously over the ranks (64 -> 8 per GPU on 8 GPUs)")
     ap.add_argument("--frames", type=int, default=102, help="TDMA frames per stream (gsm_sync_demod.m:23)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic streams per GPU (tiled to --streams)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic streams per GPU (tiled to --streams when fewer)")
     ap.add_argument("--mode", choices=["table", "stream"], default="table",
                     help="table: ppm table + pos_info only (2 B/sample); stream: also write r_correct (18 B/sample)")
     ap.add_argument("--workload", choices=["calib", "scan"], default="calib",
@@ -58,6 +58,44 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed HIP-event passes (roofline kernel figure, breakdown)")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-results (config 2, stream mode, scanner path)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _gen_one(job):
+    dongle, frames, kw = job
+    from gsmcal import synth
+    return synth.make_stream(dongle=dongle, num_frames=frames, **kw)[0]
+
+
+def gen_streams(jobs):
+    """Synthetic captures for `jobs` = [(dongle, frames, kwargs)], one worker process per host core (0.5 s of NumPy per
+    stream).  Called BEFORE this process touches the GPU: the workers are forked from a process without HIP state."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(ncpu, 32, len(jobs)))
+    if workers == 1:
+        return [_gen_one(j) for j in jobs]
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(_gen_one, jobs, chunksize=1))
+
+
+def mixed_kwargs(n, seed):
+    """The widened distribution of tests/sweep_parity.py: every 5th stream at 5-15 dB, every 7th with up to +-300 ppm of
+    sampling error, every 11th without a BCCH carrier, every 13th with up to +-60 ppm of carrier error."""
+    rng = np.random.default_rng(seed)
+    kws = []
+    for i in range(n):
+        kw = {}
+        if i % 5 == 1:
+            kw["snr_db"] = float(rng.uniform(5, 15))
+        if i % 7 == 2:
+            kw["sampling_ppm"] = float(rng.uniform(-300, 300))
+        if i % 11 == 3:
+            kw["bcch"] = False
+        if i % 13 == 4:
+            kw["carrier_ppm"] = float(rng.uniform(-60, 60))
+        kws.append(kw)
+    return kws
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -117,19 +155,83 @@ def time_steps(torch, dev, fn, steps, warmup, fence=None):
     return time.perf_counter() - t0
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as CHILDREN of this process (which has not
+    touched the GPU and never will -- no exec of a GPU-initialised process anywhere), relay rank 0's JSON line and exit
+    with the launcher's code.  The torch.distributed.run form the driver uses keeps working: it sets RANK, so this is
+    skipped."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                               # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        s_ = ln.strip()
+        if s_.startswith("{") and '"metric"' in s_:
+            line = s_                                        # rank 0's result: printed once, below
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line and rc == 0:
+        print(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if (args.gpus > 1 or os.environ.get("GSMCAL_FORCE_DIST") == "1") and "RANK" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    import torch
-    import torch.distributed as dist
-
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     import gsmcal
     from gsmcal import dist as gdist
     from gsmcal import synth
+
+    # ---- synthetic input, made on the host cores before this process touches the GPU ----
+    frames = args.frames
+    N = frames * synth.FRAME_OV
+    if args.scaling == "strong":
+        total_units = args.streams
+        lo, hi = gdist.shard_range(total_units, world, rank)
+    else:
+        total_units = args.streams * world
+        lo, hi = rank * args.streams, (rank + 1) * args.streams
+    D = hi - lo
+    if D < 1:
+        raise SystemExit("more ranks than streams")
+    nd = max(1, min(args.distinct, D))
+    cand_jobs, cand_raw, mixed_raw = [], [], None
+    if args.workload == "calib":
+        ncand = nd + nd // 3 + 8                             # about one synthetic seed in eight is rejected by the fine search
+        cand_jobs = [(100000 * rank + lo + i, frames, {}) for i in range(ncand)]
+        jobs = list(cand_jobs)
+        n_mixed = 64 if (world == 1 and not args.no_sub and args.mode == "table") else 0
+        jobs += [(5000 + i, frames, kw) for i, kw in enumerate(mixed_kwargs(n_mixed, 5000))]
+        raws = gen_streams(jobs)
+        cand_raw = raws[:ncand]
+        mixed_raw = np.stack(raws[ncand:]) if n_mixed else None
+
+    import torch
+    import torch.distributed as dist
+
+    ndev = torch.cuda.device_count()                         # (counting devices does not initialise the GPU)
+    if ndev < world or local_rank >= ndev:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} devices, this node exposes {ndev} "
+                         "(one process per GPU; GSMCAL_FORCE_DIST=1 with --gpus 1 exercises the RCCL path on one device)")
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -143,48 +245,41 @@ def main():
 
     if args.workload == "scan":
         return bench_scan_main(args, rank, world, dev, use_dist)
-    frames = args.frames
-    N = frames * synth.FRAME_OV
     fc = 957.4e6                                            # gsm_sync_demod.m:14
     coef = np.ascontiguousarray(synth.fir1(46, 200e3 / synth.FS))   # gsm_sync_demod.m:34
     ts = np.ascontiguousarray(synth.sch_training_sequence())
     # units of this rank: weak scaling = --streams per GPU; strong = --streams in total, block-contiguous shards
-    if args.scaling == "strong":
-        total_units = args.streams
-        lo, hi = gdist.shard_range(total_units, world, rank)
-    else:
-        total_units = args.streams * world
-        lo, hi = rank * args.streams, (rank + 1) * args.streams
-    D = hi - lo
-    if D < 1:
-        raise SystemExit("more ranks than streams")
     sizes = gdist.shard_sizes(total_units, world) if args.scaling == "strong" else [args.streams] * world
     Dmax = max(sizes)
 
-    # ---- synthetic input, resident in HBM before the timed region (unit u = global stream index) ----
-    nd = max(1, min(args.distinct, D))
+    # ---- resident in HBM before the timed region (unit u = global stream index) ----
     # The reference's fine search rejects streams whose FCCH tone falls between two FFT bins (about one synthetic stream in
     # eight: tests/test_oracle_cpu.py::test_fine_search_rejection_rate_on_bin_vs_half_bin); such a stream leaves the chain
-    # after the fine search and would make the step cheaper than a calibrated one.  The benchmark therefore takes the first
-    # `nd` seeds of its range that the chain calibrates (status 0), so every stream does the full work.
+    # after the fine search and would make the step cheaper than a calibrated one.  The headline batch therefore takes the
+    # first `nd` seeds of its range that the chain calibrates (status 0), so every stream does the full work; the
+    # unselected distribution (low SNR, large ppm, carriers without a BCCH) is timed as sub_results.mixed_batch.
     stream0 = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream0):
         ctx0 = gsmcal.Context(local_rank, stream=stream0.cuda_stream)
         picked, skipped, cand = [], [], 0
-        while len(picked) < nd and cand < 8 * nd + 16:
-            batch = [synth.make_stream(dongle=100000 * rank + lo + cand + i, num_frames=frames)[0] for i in range(nd)]
-            res = gsmcal.calibrate_batch(np.stack(batch), coef, ts, fc, ctx=ctx0)
-            for i in range(nd):
+        while len(picked) < nd and cand < 8 * nd + 64:
+            if cand >= len(cand_raw):                        # (rare) the first draw held too many rejected seeds
+                more = [(100000 * rank + lo + cand + i, frames, {}) for i in range(16)]
+                cand_raw += [_gen_one(jb) for jb in more]
+            hi_c = min(len(cand_raw), cand + 64)
+            res = gsmcal.calibrate_batch(np.stack(cand_raw[cand:hi_c]), coef, ts, fc, ctx=ctx0)
+            for i in range(hi_c - cand):
                 if res["table"][i, 9] == 0 and len(picked) < nd:
-                    picked.append(batch[i])
+                    picked.append(cand_raw[cand + i])
                 elif res["table"][i, 9] != 0:
                     skipped.append(cand + i)
-            cand += nd
+            cand = hi_c
         ctx0.close()
     if len(picked) < nd:
         raise SystemExit("could not find enough calibratable synthetic streams")
     distinct = np.stack(picked)
-    raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device
+    del cand_raw
+    raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()   # tiled on the device when nd < D
 
     # a dedicated (non-default) stream: the library forks its internal lanes off this stream, and torch's copies and
     # collectives are enqueued on it too, so one synchronize covers the whole step
@@ -229,19 +324,38 @@ def main():
     last = ((nstep[0] - 1) & 1) if use_dist else 0
     table = cal.table(last).numpy().copy()
 
-    # ---- every rank checks rows of its OWN shard against the CPU oracle before anything is reported ----
+    # ---- every rank checks rows of its OWN shard against the CPU oracle before anything is reported, whatever the
+    # flags (the check used to ride on the CPU-baseline leg) ----
     from oracle import gsmcal_oracle as oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
     det = gsmcal.last_batch_details(min(D, nd), ctx=ctx)
     pos_host = cal.pos_t.cpu().numpy()
     n_rank_checked = 0
-    for i in ([0] if world > 1 else []):
-        parity.compare_stream(oracle.calibrate_stream(distinct[i], coef, ts, fc), table[i], det, i, _pos_info(pos_host, table, i))
+    orc_rows = {}
+    for i in range(min(nd, 4)):
+        orc_rows[i] = oracle.calibrate_stream(distinct[i], coef, ts, fc)
+        parity.compare_stream(orc_rows[i], table[i], det, i, _pos_info(pos_host, table, i))
         n_rank_checked += 1
+    gathered_ok = None
     if use_dist:
-        assert np.array_equal(tg.own_rows(last).cpu().numpy(), table, equal_nan=True), "all-gathered table differs from this rank's rows"
+        # the collective's result, checked against what every rank says it sent: digests of the local tables travel
+        # through a second, independent group (gloo over TCP), and each rank compares every peer's block of the
+        # RCCL-gathered table with that peer's digest -- not only its own rows
+        import hashlib
         assert host_gath[last].shape[0] == sum(sizes)
+        mine = hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest()
+        chk = dist.new_group(backend="gloo")
+        digests = [None] * world
+        dist.all_gather_object(digests, mine, group=chk)
+        g_all = host_gath[last].numpy()
+        off = 0
+        for r in range(world):
+            blk = np.ascontiguousarray(g_all[off: off + sizes[r]])
+            assert hashlib.sha256(blk.tobytes()).hexdigest() == digests[r], f"rank {rank}: rank {r}'s rows in the gathered table differ from what it sent"
+            off += sizes[r]
+        assert np.array_equal(tg.own_rows(last).cpu().numpy(), table, equal_nan=True), "all-gathered table differs from this rank's rows"
+        gathered_ok = True
 
     n_ok = int(np.sum(table[:, 9] == 0))
     total_samples = sum(sizes) * N * args.steps
@@ -253,13 +367,16 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64",
         "data": f"synthetic 8x-oversampled GSM BCCH-carrier uint8 IQ (seed {synth.DEFAULT_SEED}); {nd} distinct "
-                f"streams per GPU tiled to {D} (the first {nd} seeds the chain calibrates; {len(skipped)} rejected seeds skipped)",
+                f"streams per GPU" + (f" tiled to {D}" if nd < D else "") + f" (the first {nd} seeds the chain calibrates; "
+                f"{len(skipped)} rejected seeds skipped; SNR 15-30 dB -- the unselected low-SNR / large-ppm / no-BCCH mix is "
+                "sub_results.mixed_batch)",
         "config": {"workload": f"cfg4 full chain gsm_sync_demod.m:107-124: {sum(sizes)} dongle streams ({Dmax}/GPU) x {N} IQ samples "
                                f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation, table on the host",
                    "streams_per_gpu": Dmax, "streams_total": sum(sizes), "samples_per_stream": N, "output": args.mode,
                    "bytes_per_sample_algorithmic": bps,
                    "collective": "all_gather(table) over RCCL" if use_dist else "none",
-                   "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked},
+                   "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked,
+                   "gathered_table_checked_against_every_rank": gathered_ok},
     }
     if rank == 0:
         path_gbs = value * 1e6 * bps / 1e9
@@ -294,7 +411,7 @@ def main():
                                                 "bound": "latency (serial fp64 dependency chains, one to three workgroups per CU)"}
         out["roofline"] = roof
         if world == 1 and not args.no_sub:
-            out["sub_results"] = sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream)
+            out["sub_results"] = sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mixed_raw, distinct)
         # ---- CPU baseline: the oracle (fp64 NumPy/SciPy restatement) on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             done, t_cpu, checked = 0, 0.0, 0
@@ -311,7 +428,7 @@ def main():
                                    "kind": "port",
                                    "sample": f"{done} streams x {N} samples through oracle.calibrate_stream "
                                              f"(NumPy/SciPy fp64 restatement, 1 thread) in {t_cpu:.1f} s"}
-            out["parity_checked_streams"] = checked
+            out["parity_checked_streams"] = max(checked, n_rank_checked)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
             # the same restatement on every host core (one worker process per core over independent streams): SURVEY 8d
             # asks for the all-core figure next to the single-thread one
@@ -328,6 +445,8 @@ def main():
                                                  "kind": "port",
                                                  "sample": f"{nrun} streams over {ncpu} worker processes in {t_all:.1f} s"}
                 out["speedup_vs_cpu_all_cores"] = round(value / out["cpu_baseline_all_cores"]["value"], 1)
+        if "parity_checked_streams" not in out:
+            out["parity_checked_streams"] = n_rank_checked
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -363,11 +482,93 @@ def pmc_traffic(kernel, D, N):
     return None, "kernel not in the committed PMC pass"
 
 
-def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream):
-    """The other BASELINE configurations, timed in this same (driver-run) process."""
+def time_calib(torch, gsmcal, dev, ctx, raw_t, N, coef, ts, fc, K, W):
+    """ms per step of one more table-mode batch on `ctx` + its table"""
+    c2 = Calib(torch, gsmcal, dev, ctx, raw_t, N, "table", coef, ts, fc)
+
+    def st():
+        c2.launch(0)
+        c2.to_host(0)
+    t = time_steps(torch, dev, st, K, W) / K
+    torch.cuda.synchronize(dev)
+    return t, c2.table(0).numpy().copy(), c2
+
+
+def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mixed_raw=None, distinct=None):
+    """The other BASELINE configurations and regimes, timed in this same (driver-run) process."""
     from gsmcal import synth
+    from oracle import gsmcal_oracle as oracle
+    import parity
     sub = {}
     K, W = args.steps, max(2, args.warmup)
+    bps = 2
+
+    def path(v):
+        return {"path_GBps": round(v * 1e6 * bps / 1e9, 1), "path_frac_of_hbm": round(v * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4)}
+    # (i) the unselected distribution: low SNR, large ppm, carriers without a BCCH, rejected seeds left in
+    if mixed_raw is not None and args.mode == "table":
+        try:
+            mt = torch.from_numpy(mixed_raw).to(dev)
+            t, tab, c2 = time_calib(torch, gsmcal, dev, ctx, mt, N, coef, ts, fc, K, W)
+            det = gsmcal.last_batch_details(len(mixed_raw), ctx=ctx)
+            pos = c2.pos_t.cpu().numpy()
+            nchk = 0
+            for i in (1, 2, 3, 4, 6, 9):                     # one of each kind of the mix + plain ones
+                try:
+                    orc = oracle.calibrate_stream(mixed_raw[i], coef, ts, fc)
+                except oracle.MatlabIndexError:              # where MATLAB would stop with an index error the ABI reports a negative status
+                    assert tab[i, 9] < 0
+                    continue
+                parity.compare_stream(orc, tab[i], det, i, _pos_info(pos, tab, i))
+                nchk += 1
+            v = len(mixed_raw) * N / t / 1e6
+            sub["mixed_batch"] = {"streams": len(mixed_raw), "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
+                                  "streams_calibrated_ok": int(np.sum(tab[:, 9] == 0)), "rows_checked_vs_oracle": nchk,
+                                  "what": "64 distinct streams drawn like tests/sweep_parity.py (every 5th at 5-15 dB, every 7th up to "
+                                          "+-300 ppm sampling error, every 11th without BCCH, every 13th up to +-60 ppm carrier "
+                                          "error), nothing pre-selected"}
+            del c2, mt
+        except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
+            sub["mixed_batch"] = {"error": repr(e)}
+    # (ii) the fine search's worst case: no certificate, every 64-shift chunk of every window is swept (GSMCAL_CERT=0)
+    if args.mode == "table":
+        try:
+            os.environ["GSMCAL_CERT"] = "0"
+            s2 = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s2):
+                cx = gsmcal.Context(dev.index or 0, stream=s2.cuda_stream)
+                os.environ.pop("GSMCAL_CERT", None)
+                t, tab, c2 = time_calib(torch, gsmcal, dev, cx, cal.raw_t, N, coef, ts, fc, max(3, K // 4), 2)
+                same = bool(np.array_equal(tab, cal.table(0).numpy(), equal_nan=True))
+                del c2
+                cx.close()
+            v = cal.D * N / t / 1e6
+            sub["fine_search_worst_case_no_certificate"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
+                                                            **path(v), "table_identical_to_headline": same}
+        except Exception as e:  # noqa: BLE001
+            sub["fine_search_worst_case_no_certificate"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("GSMCAL_CERT", None)
+    # (iii) the throughput regime: 1 024 streams per GPU (the distinct set tiled; up to four lanes)
+    if args.mode == "table" and cal.D < 1024:
+        try:
+            reps = (1024 + cal.D - 1) // cal.D
+            big = cal.raw_t.repeat((reps, 1))[:1024].contiguous()
+            t, tab, c2 = time_calib(torch, gsmcal, dev, ctx, big, N, coef, ts, fc, max(5, K // 2), 3)
+            v = 1024 * N / t / 1e6
+            ref = cal.table(0).numpy()
+            same = all(np.array_equal(tab[k * cal.D: (k + 1) * cal.D], ref[: len(tab[k * cal.D: (k + 1) * cal.D])], equal_nan=True) for k in range(reps))
+            sub["streams_1024"] = {"streams": 1024, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
+                                   "tables_identical_to_headline": bool(same)}
+            if not args.no_kernel_events:
+                prof = event_pass(ctx, lambda: c2.launch(0), 5, torch, dev)
+                sub["streams_1024"]["kernels_ms_per_step_untimed_pass"] = {k: round(v_[0] / 5, 4) for k, v_ in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            del c2, big
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            sub["streams_1024"] = {"error": repr(e)}
+        cal.launch(0)
+        torch.cuda.synchronize(dev)
     # config 2: gsm_sync_demod.m on 2 dongle streams (latency-bound)
     if cal.D >= 2 and args.mode == "table":
         def two():
@@ -396,9 +597,12 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream):
     # scanner path: BASELINE config 3 (200 captures) and config 5 per GPU (12 800 captures, 16.4 GB, generated on the device)
     for name, ncap in (("config3_scan_200", 200), ("config5_scan_12800_per_gpu", 12800)):
         try:
-            r = bench_scan(args, torch, gsmcal, dev, ctx, ncap, 64, distinct=32, steps=max(5, K // 2), warmup=2, cpu=False)
+            r = bench_scan(args, torch, gsmcal, dev, ctx, ncap, 64, distinct=32, steps=max(5, K // 2), warmup=2, cpu=(ncap == 200))
             sub[name] = {k: r[k] for k in ("ms_per_step", "value", "hbm_GBps_algorithmic", "path_frac_of_hbm", "captures_with_hits",
                                            "kernels_ms_per_step_untimed_pass", "parity_checked_captures") if k in r}
+            if "cpu_baseline" in r:     # BASELINE config 1: the CPU-only FCCH_coarse_position path on 640 000-sample captures
+                sub["config1_cpu_scan_path"] = dict(r["cpu_baseline"], what="config 1: raw2iq + fir1(30) + 1:64 + FCCH_coarse_position "
+                                                    "+ acceptance on 640 000-sample captures, oracle (NumPy port) on one host thread")
             sub[name]["captures"] = ncap
         except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
             sub[name] = {"error": repr(e)}

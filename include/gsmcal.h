@@ -252,6 +252,20 @@ typedef struct gsmcal_comm gsmcal_comm;
 int gsmcal_comm_get_unique_id(void* id_out /* GSMCAL_COMM_ID_BYTES */);
 int gsmcal_comm_init_rank(gsmcal_ctx* ctx, const void* id, int world, int rank, gsmcal_comm** out);
 int gsmcal_comm_init_file(gsmcal_ctx* ctx, const char* path, int world, int rank, gsmcal_comm** out);
+/* The id file is run-specific: it carries a magic word and a 64-bit nonce next to the id.  Rank 0 removes whatever sits at
+ * `path` before it generates the id, publishes the new file by an atomic rename, and removes it again once the communicator
+ * is up (ncclCommInitRank returns only after every rank has joined), so a file survives only a crashed bootstrap.  Readers
+ * accept nothing but a complete file with the right magic AND the caller's nonce; with nonce 0 ("none", what
+ * gsmcal_comm_init_file passes unless GSMCAL_COMM_NONCE is set in the environment) they instead refuse files older than
+ * GSMCAL_COMM_STALE_S seconds (default 120).  Give every launch its own nonce (job id, launcher pid, start time). */
+int gsmcal_comm_init_file_nonce(gsmcal_ctx* ctx, const char* path, unsigned long long nonce, int world, int rank,
+                                gsmcal_comm** out);
+/* The file protocol alone (no GPU, no RCCL; what the two functions above run before ncclCommInitRank): rank 0 publishes
+ * id_inout, the other ranks wait up to timeout_s seconds for it and receive it in id_inout.  GSMCAL_E_ARG on time-out.
+ * gsmcal_comm_id_file_remove: rank 0's clean-up after the communicator is up. */
+int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int world, int rank,
+                                 void* id_inout /* GSMCAL_COMM_ID_BYTES */, double timeout_s);
+int gsmcal_comm_id_file_remove(const char* path);
 void gsmcal_comm_destroy(gsmcal_comm* comm);
 /* d_all[r][i][c] = rank r's d_local[i][c]: rows_per_rank x cols doubles per rank (ranks with fewer units pad their block,
  * e.g. with NaN); device pointers; enqueued on the context's stream (gsmcal_sync() before reading d_all on the host). */

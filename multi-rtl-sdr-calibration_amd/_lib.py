@@ -71,6 +71,9 @@ SIGNATURES = {
     "gsmcal_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "gsmcal_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmcal_comm_init_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_comm_init_file_nonce": (C.c_int, [C.c_void_p, C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_comm_id_file_exchange": (C.c_int, [C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_double]),
+    "gsmcal_comm_id_file_remove": (C.c_int, [C.c_char_p]),
     "gsmcal_comm_destroy": (None, [C.c_void_p]),
     "gsmcal_allgather_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gsmcal_ring_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),

@@ -15,6 +15,8 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -76,8 +78,13 @@ struct gsmcal_ctx {
         int seen = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-    } g_calib[2], g_scan;           // two calibration graphs: callers that alternate between two output tables keep both
-    unsigned g_calib_lru = 0;
+        unsigned long used = 0;     // stamp of the last call that took this slot (least recently used one is recycled)
+    };
+    // callers that alternate between buffers (two output tables; the ingest ring's device slots) keep one graph per
+    // combination: GRAPH_SLOTS keys per entry point, least recently used one recycled
+    static constexpr int GRAPH_SLOTS = 4;
+    GraphSlot g_calib[GRAPH_SLOTS], g_scan[GRAPH_SLOTS];
+    unsigned long g_stamp = 0;
     unsigned long ws_epoch = 0;     // bumped whenever a workspace buffer is (re)allocated or a parameter upload happens
     bool use_graph = true;          // GSMCAL_GRAPH=0 disables
     bool graph_always = false;      // GSMCAL_GRAPH=2: also single-stream plans (default: only plans that fork onto internal streams)
@@ -559,6 +566,25 @@ size_t coarse_scan_lds(long nwin, int mv_len) {
     return coarse_scan_lds_fixed() + (size_t)(nwin + mv_len + 128) * sizeof(double);
 }
 
+// Partial tap sums of the head rows (see coarse()): uploaded on the context's stream BEFORE fork_lanes(), so the fork
+// event orders the copy ahead of every lane's k_coarse_snr (inside coarse() only lane 0 was ordered behind it).
+int ensure_head(gsmcal_ctx* c, int front_decim) {
+    const int ntaps = (int)c->h_coef.size();
+    const int n_head = ntaps > 1 ? (ntaps - 1 + front_decim - 1) / front_decim : 1;
+    if ((int)c->h_head.size() == n_head && c->head_epoch == c->coef_epoch && c->csum_head.p) return 0;
+    c->h_head.assign(n_head, 0.0);
+    for (int j = 0; j < n_head; ++j) {
+        double h = 0.0;
+        for (int k = 0; k < ntaps && k <= (long)front_decim * j; ++k) h += c->h_coef[k];
+        c->h_head[j] = h;
+    }
+    RET_IF(ensure(c, c->csum_head, (size_t)n_head * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(c->csum_head.p, c->h_head.data(), (size_t)n_head * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->head_epoch = c->coef_epoch;
+    ++c->ws_epoch;
+    return 0;
+}
+
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
            bool mean_corr = false, long n0 = 0, int front_decim = 64, const ScanAccept* accept = nullptr) {
     CoarseArgs a;
@@ -572,21 +598,11 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
         double cs = 0.0;
         for (double v : c->h_coef) cs += v;
         a.csum_all = cs;
-        // decimated rows j with front_decim*j < ntaps-1 see only taps 0..front_decim*j (zero initial state of filter())
+        // decimated rows j with front_decim*j < ntaps-1 see only taps 0..front_decim*j (zero initial state of filter()):
+        // their partial tap sums were uploaded by ensure_head() before the lanes forked
         const int ntaps = (int)c->h_coef.size();
         const int n_head = ntaps > 1 ? (ntaps - 1 + front_decim - 1) / front_decim : 1;
-        if ((int)c->h_head.size() != n_head || c->head_epoch != c->coef_epoch) {
-            c->h_head.assign(n_head, 0.0);
-            for (int j = 0; j < n_head; ++j) {
-                double h = 0.0;
-                for (int k = 0; k < ntaps && k <= (long)front_decim * j; ++k) h += c->h_coef[k];
-                c->h_head[j] = h;
-            }
-            RET_IF(ensure(c, c->csum_head, (size_t)n_head * sizeof(double)));
-            HIPCHK(c, hipMemcpyAsync(c->csum_head.p, c->h_head.data(), (size_t)n_head * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            c->head_epoch = c->coef_epoch;
-            ++c->ws_epoch;
-        }
+        if ((int)c->h_head.size() != n_head || c->head_epoch != c->coef_epoch) { c->err = "coarse(): csum_head not prepared"; return GSMCAL_E_ARG; }
         a.csum_head = (const double*)c->csum_head.p;
         a.n_head = n_head;
     }
@@ -772,6 +788,19 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
     return rc;
 }
 
+// the slot holding `key`, else the least recently used one
+gsmcal_ctx::GraphSlot& pick_slot(gsmcal_ctx* c, gsmcal_ctx::GraphSlot* slots, const std::vector<uintptr_t>& key) {
+    int pick = 0;
+    bool hit = false;
+    for (int i = 0; i < gsmcal_ctx::GRAPH_SLOTS && !hit; ++i)
+        if (slots[i].key == key) { pick = i; hit = true; }
+    if (!hit)
+        for (int i = 1; i < gsmcal_ctx::GRAPH_SLOTS; ++i)
+            if (slots[i].used < slots[pick].used) pick = i;
+    slots[pick].used = ++c->g_stamp;
+    return slots[pick];
+}
+
 int positive_status(const StreamState& st, int stage) {
     if (st.status < 0) return st.status;
     return st.stage_status[stage];
@@ -910,10 +939,11 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->fork) (void)hipEventDestroy(c->fork);
-    for (auto* g : {&c->g_calib[0], &c->g_calib[1], &c->g_scan}) {
-        if (g->exec) (void)hipGraphExecDestroy(g->exec);
-        if (g->graph) (void)hipGraphDestroy(g->graph);
-    }
+    for (int i = 0; i < gsmcal_ctx::GRAPH_SLOTS; ++i)
+        for (auto* g : {&c->g_calib[i], &c->g_scan[i]}) {
+            if (g->exec) (void)hipGraphExecDestroy(g->exec);
+            if (g->graph) (void)hipGraphDestroy(g->graph);
+        }
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1385,6 +1415,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     }
     c->cur = &c->lanes[0];
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
+    RET_IF(ensure_head(c, decim));
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
                                         (uintptr_t)d_snr_numhit, (uintptr_t)d_positions, (uintptr_t)d_pos_snr,
                                         (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg, (uintptr_t)c->params_epoch};
@@ -1415,7 +1446,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(join_lanes(c, nl));
     return 0;
     };
-    RET_IF(run_maybe_graph(c, c->g_scan, key, enqueue, plan_lanes(c, d, false) > 1));
+    RET_IF(run_maybe_graph(c, pick_slot(c, c->g_scan, key), key, enqueue, plan_lanes(c, d, false) > 1));
     plan_lanes(c, d, false);
     c->cur = &c->lanes[0];
     c->last_S = d;
@@ -1459,6 +1490,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
     RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));
+    RET_IF(ensure_head(c, decim));
     RET_IF(ensure_twiddles(c, g.nfft));
     // independent streams: split over lanes (HIP streams) so latency-bound stages of one group overlap the
     // compute-bound fine search of another; a repeated call is replayed as one hipGraph
@@ -1502,12 +1534,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(join_lanes(c, nl));
     return 0;
     };
-    int slot = 0;                                            // the slot holding this key, else the one not used last
-    if (c->g_calib[0].key == key) slot = 0;
-    else if (c->g_calib[1].key == key) slot = 1;
-    else slot = 1 - (int)(c->g_calib_lru & 1u);
-    c->g_calib_lru = (unsigned)slot;
-    RET_IF(run_maybe_graph(c, c->g_calib[slot], key, enqueue, plan_lanes(c, d) > 1));
+    RET_IF(run_maybe_graph(c, pick_slot(c, c->g_calib, key), key, enqueue, plan_lanes(c, d) > 1));
     plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
     c->cur = &c->lanes[0];
     c->last_S = d;
@@ -1600,26 +1627,73 @@ int gsmcal_comm_init_rank(gsmcal_ctx* c, const void* idp, int world, int rank, g
     return 0;
 }
 
-int gsmcal_comm_init_file(gsmcal_ctx* c, const char* path, int world, int rank, gsmcal_comm** out) {
-    if (!c || !path || !out || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
-    unsigned char id[GSMCAL_COMM_ID_BYTES];
+// ---- id-file bootstrap: [8 B magic | 8 B nonce | 128 B id], run-specific (see include/gsmcal.h) ----
+static const unsigned long long GSMCAL_ID_MAGIC = 0x3144494c41434d47ull;   // "GMCALID1"
+
+int gsmcal_comm_id_file_remove(const char* path) {
+    if (!path) return GSMCAL_E_ARG;
+    (void)unlink(path);
+    (void)unlink((std::string(path) + ".tmp").c_str());
+    return 0;
+}
+
+int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int world, int rank, void* id_inout, double timeout_s) {
+    if (!path || !id_inout || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
+    const size_t rec = 16 + GSMCAL_COMM_ID_BYTES;
+    unsigned char buf[16 + GSMCAL_COMM_ID_BYTES];
     if (rank == 0) {
-        RET_IF(gsmcal_comm_get_unique_id(id));
+        (void)gsmcal_comm_id_file_remove(path);                           // whatever an earlier (crashed) bootstrap left behind
+        memcpy(buf, &GSMCAL_ID_MAGIC, 8);
+        memcpy(buf + 8, &nonce, 8);
+        memcpy(buf + 16, id_inout, GSMCAL_COMM_ID_BYTES);
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); c->err = "cannot write the id file"; return GSMCAL_E_ARG; }
-        fclose(f);
-        if (rename(tmp.c_str(), path) != 0) { c->err = "cannot publish the id file"; return GSMCAL_E_ARG; }   // atomic: readers never see half an id
-    } else {
-        bool ok = false;
-        for (int tries = 0; tries < 6000 && !ok; ++tries) {             // up to ~60 s
-            FILE* f = fopen(path, "rb");
-            if (f) { ok = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
-            if (!ok) usleep(10000);
-        }
-        if (!ok) { c->err = "timed out waiting for rank 0's id file"; return GSMCAL_E_ARG; }
+        if (!f || fwrite(buf, 1, rec, f) != rec) { if (f) fclose(f); return GSMCAL_E_ARG; }
+        if (fclose(f) != 0) return GSMCAL_E_ARG;
+        if (rename(tmp.c_str(), path) != 0) return GSMCAL_E_ARG;          // atomic: readers never see half a record
+        return 0;
     }
-    return gsmcal_comm_init_rank(c, id, world, rank, out);
+    double stale_s = 120.0;
+    if (const char* e = getenv("GSMCAL_COMM_STALE_S")) { const double v = atof(e); if (v > 0.0) stale_s = v; }
+    const long tries = (long)(timeout_s > 0.0 ? timeout_s * 100.0 : 6000.0);
+    for (long t = 0; t < tries; ++t) {
+        FILE* f = fopen(path, "rb");
+        if (f) {
+            const size_t got = fread(buf, 1, rec, f);
+            const bool more = got == rec && fgetc(f) != EOF;
+            struct stat sb;
+            const bool have_sb = fstat(fileno(f), &sb) == 0;
+            fclose(f);
+            unsigned long long magic = 0, fn = 0;
+            memcpy(&magic, buf, 8);
+            memcpy(&fn, buf + 8, 8);
+            bool ok = got == rec && !more && magic == GSMCAL_ID_MAGIC && fn == nonce;
+            // no nonce to tell runs apart: a record older than the stale window belongs to a bootstrap that died
+            if (ok && nonce == 0) ok = have_sb && difftime(time(nullptr), sb.st_mtime) <= stale_s;
+            if (ok) { memcpy(id_inout, buf + 16, GSMCAL_COMM_ID_BYTES); return 0; }
+        }
+        usleep(10000);
+    }
+    return GSMCAL_E_ARG;
+}
+
+int gsmcal_comm_init_file_nonce(gsmcal_ctx* c, const char* path, unsigned long long nonce, int world, int rank, gsmcal_comm** out) {
+    if (!c || !path || !out || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
+    unsigned char id[GSMCAL_COMM_ID_BYTES];
+    if (rank == 0) RET_IF(gsmcal_comm_get_unique_id(id));
+    if (gsmcal_comm_id_file_exchange(path, nonce, world, rank, id, 60.0) != 0) {
+        c->err = rank == 0 ? "cannot publish the id file" : "timed out waiting for rank 0's id file (this run's nonce)";
+        return GSMCAL_E_ARG;
+    }
+    const int rc = gsmcal_comm_init_rank(c, id, world, rank, out);
+    if (rank == 0) (void)gsmcal_comm_id_file_remove(path);              // every rank has joined (or the bootstrap failed): the id is spent
+    return rc;
+}
+
+int gsmcal_comm_init_file(gsmcal_ctx* c, const char* path, int world, int rank, gsmcal_comm** out) {
+    unsigned long long nonce = 0;
+    if (const char* e = getenv("GSMCAL_COMM_NONCE")) nonce = strtoull(e, nullptr, 0);
+    return gsmcal_comm_init_file_nonce(c, path, nonce, world, rank, out);
 }
 
 void gsmcal_comm_destroy(gsmcal_comm* g) {

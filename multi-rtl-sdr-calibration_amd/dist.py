@@ -93,15 +93,18 @@ class TableGatherer:
 
 class NativeComm:
     """The same collective without PyTorch: gsmcal_allgather_table of the C ABI (RCCL, enqueued on the context's
-    stream).  Bootstrap by a file every rank can see (rank 0 writes the 128-byte id) or by an id passed in."""
+    stream).  Bootstrap by a file every rank can see (rank 0 writes the 128-byte id together with the
+    launch's `nonce`; the others accept only a record carrying it) or by an id passed in."""
 
-    def __init__(self, ctx, world, rank, id_file=None, unique_id=None):
+    def __init__(self, ctx, world, rank, id_file=None, unique_id=None, nonce=None):
         import ctypes as C
         self.ctx, self.world, self.rank = ctx, int(world), int(rank)
         h = C.c_void_p()
         if unique_id is not None:
             buf = C.create_string_buffer(bytes(unique_id), 128)
             rc = ctx.lib.gsmcal_comm_init_rank(ctx.h, buf, self.world, self.rank, C.byref(h))
+        elif nonce is not None:       # run-specific id file: readers ignore anything an earlier launch left at the path
+            rc = ctx.lib.gsmcal_comm_init_file_nonce(ctx.h, str(id_file).encode(), int(nonce) & (2**64 - 1), self.world, self.rank, C.byref(h))
         else:
             rc = ctx.lib.gsmcal_comm_init_file(ctx.h, str(id_file).encode(), self.world, self.rank, C.byref(h))
         ctx.check(rc, "gsmcal_comm_init")

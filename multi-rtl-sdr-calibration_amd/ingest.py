@@ -59,16 +59,23 @@ def _matlab_uint32(v):
 
 def read_exact(sock, view, timeout=1.0):
     """fread(tcp_obj, n, 'uint8') with the driver's 1 s timeout (gsm_sync_demod.m:64): fills `view` (a writable
-    memoryview) and returns the number of bytes actually received -- fewer than asked for on a timeout or a closed peer."""
-    sock.settimeout(timeout)
+    memoryview) and returns the number of bytes actually received -- fewer than asked for on a timeout or a closed peer.
+    MATLAB's Timeout bounds the WHOLE fread, so there is one deadline for the call, not one per recv (a peer trickling a
+    byte every 0.9 s would otherwise hold a capture for ever)."""
+    import time
+    deadline = time.monotonic() + timeout
     got, n = 0, len(view)
     try:
         while got < n:
+            left = deadline - time.monotonic()
+            if left <= 0.0:
+                break
+            sock.settimeout(left)
             k = sock.recv_into(view[got:], n - got)
             if k == 0:
                 break
             got += k
-    except socket.timeout:
+    except (socket.timeout, BlockingIOError):
         pass
     return got
 
@@ -80,6 +87,8 @@ class RtlTcpDongle:
         self.sock = socket.create_connection((host, port), timeout=timeout)
         self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         self.timeout = timeout
+        self.parity = 0                 # 1: an odd number of stream bytes consumed so far (next byte is a Q)
+        self.last_flush_short = False
 
     def configure(self, gain, sampling_rate, freq):
         set_gain_tcp(self.sock, gain)          # gsm_sync_demod.m:71-73
@@ -87,12 +96,26 @@ class RtlTcpDongle:
         set_freq_tcp(self.sock, freq)           # :81-83
 
     def flush(self, nbytes):
-        """:86-89 -- read and discard 2*num_sample bytes (rtl_tcp's 12-byte greeting is the head of them)."""
+        """:86-89 -- read and discard 2*num_sample bytes (rtl_tcp's 12-byte greeting is the head of them).  Returns the
+        number of bytes discarded; fewer than nbytes means the dongle is not streaming yet (the caller decides)."""
         scratch = memoryview(bytearray(nbytes))
-        return read_exact(self.sock, scratch, self.timeout)
+        got = read_exact(self.sock, scratch, self.timeout)
+        self.parity ^= got & 1
+        self.last_flush_short = got < nbytes
+        return got
 
     def capture_into(self, view):
-        return read_exact(self.sock, view, self.timeout)
+        """One capture.  The byte stream is I,Q,I,Q,...: a read that stopped after an odd number of bytes would leave the
+        NEXT capture starting on a Q byte (I and Q swapped for good), so the pairing is restored first by dropping one
+        byte -- the reference never notices this (it only re-reads, gsm_sync_demod.m:97-104)."""
+        if self.parity:
+            one = memoryview(bytearray(1))
+            self.parity ^= read_exact(self.sock, one, self.timeout) & 1
+            if self.parity:
+                return 0                                   # still mid-pair: report a short capture, the caller retries
+        got = read_exact(self.sock, view, self.timeout)
+        self.parity ^= got & 1
+        return got
 
     def close(self):
         try:

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Multi-GPU check, for whoever has a node with N >= 2 MI355X (the build box has one GPU, the CPU suite covers the
+layout under gloo: tests/test_dist_cpu.py).  One process per GPU; runs BOTH collectives on real calibration tables:
+
+    python tests/multigpu_check.py --gpus N                          (starts its own ranks)
+    python -m torch.distributed.run --nproc-per-node N tests/multigpu_check.py --gpus N
+
+  1. units = 7 synthetic dongle streams (the uneven split: shards differ by one row) and 16 (even), sharded
+     block-contiguously (gsmcal.dist.shard_range: gsm_sync_demod.m:112 / multi_rtl_sdr_gsm_FCCH_scanner.m:60-65);
+  2. every rank calibrates ITS shard on its GPU (gsmcal_calibrate_batch through the C ABI);
+  3. the table is gathered (a) by torch.distributed over RCCL (gsmcal.dist.allgather_table and the bench's double-buffered
+     TableGatherer) and (b) by the native gsmcal_allgather_table, bootstrapped through an id file carrying this launch's
+     nonce, with a stale id file of another launch planted at the path first;
+  4. every rank compares all gathered tables, row by row and bit for bit, with the table it computes for ALL units on its
+     own GPU (unit independence makes that the expected result), and rank 0 checks unit 0 against the CPU oracle.
+
+Exit code 0 and one "multigpu_check OK" line per rank on success."""
+from __future__ import annotations
+
+import argparse
+import os
+import struct
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))          # a child process: this one never touches the GPU
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=102)
+    args = ap.parse_args()
+    if "RANK" not in os.environ:
+        self_launch(args.gpus)
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    ndev = torch.cuda.device_count()
+    if ndev < world or local_rank >= ndev:
+        raise SystemExit(f"multigpu_check: {world} ranks need {world} devices, this node exposes {ndev}")
+    import gsmcal
+    from gsmcal import dist as gd
+    from gsmcal import synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
+    coef = np.ascontiguousarray(synth.fir1(46, 200e3 / synth.FS))
+    ts = np.ascontiguousarray(synth.sch_training_sequence())
+    fc = 957.4e6
+    # this launch's nonce: rank 0 draws it, everybody learns it through the process group
+    nonce_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        nonce_t[0] = int.from_bytes(os.urandom(7), "little") | 1
+    dist.broadcast(nonce_t, 0)
+    nonce = int(nonce_t.item())
+    id_path = os.path.join(tempfile.gettempdir(), "gsmcal_multigpu_check_id")
+    if rank == 0:                                    # a record another launch left behind: must be ignored by the readers
+        with open(id_path, "wb") as f:
+            f.write(struct.pack("<QQ", 0x3144494C41434D47, nonce ^ 0x55) + bytes([0xEE]) * 128)
+    dist.barrier()
+    comm = gd.NativeComm(ctx, world, rank, id_file=id_path, nonce=nonce)
+
+    for num_units in (7, 16):
+        raw = np.stack([synth.make_stream(dongle=4000 + u, num_frames=args.frames)[0] for u in range(num_units)])
+        full = gsmcal.calibrate_batch(raw, coef, ts, fc, ctx=ctx)["table"]             # expected: every unit, this GPU
+        lo, hi = gd.shard_range(num_units, world, rank)
+        sizes = gd.shard_sizes(num_units, world)
+        mx = max(sizes)
+        if hi > lo:
+            local = gsmcal.calibrate_batch(raw[lo:hi], coef, ts, fc, ctx=ctx)["table"]
+        else:
+            local = np.zeros((0, gsmcal.TABLE_COLS))
+        assert np.array_equal(local, full[lo:hi], equal_nan=True), "a shard's rows differ from the full batch (unit independence)"
+        local_t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        # (a) torch.distributed over RCCL
+        got = gd.allgather_table(local_t, num_units).cpu().numpy()
+        assert np.array_equal(got, full, equal_nan=True), f"torch all-gather, {num_units} units"
+        tg = gd.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
+        for step in range(4):                                                           # bench.py's double-buffered exchange
+            b = step & 1
+            tg.wait(b)
+            tg.post(b, local_t + float(step))
+        for b in (0, 1):
+            rows = tg.rows(b).cpu().numpy()
+            assert np.array_equal(rows, full + float(2 + b), equal_nan=True), f"TableGatherer buffer {b}, {num_units} units"
+        # (b) native collective of the C ABI: padded blocks of mx rows per rank
+        send = torch.full((mx, gsmcal.TABLE_COLS), float("nan"), dtype=torch.float64, device=dev)
+        send[: hi - lo] = local_t
+        recv = torch.zeros((world * mx, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev)
+        stream.synchronize()
+        comm.allgather_table(send.data_ptr(), mx, gsmcal.TABLE_COLS, recv.data_ptr())
+        ctx.sync()
+        r = recv.cpu().numpy()
+        nat = np.concatenate([r[k * mx: k * mx + sizes[k]] for k in range(world)])
+        assert np.array_equal(nat, full, equal_nan=True), f"native gsmcal_allgather_table, {num_units} units"
+        if rank == 0 and num_units == 7:
+            from oracle import gsmcal_oracle as oracle
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import parity
+            res = gsmcal.calibrate_batch(raw[:1], coef, ts, fc, ctx=ctx)
+            parity.compare_stream(oracle.calibrate_stream(raw[0], coef, ts, fc), res["table"][0],
+                                  gsmcal.last_batch_details(1, ctx=ctx), 0, res["pos_info"][0])
+    comm.close()
+    assert not os.path.exists(id_path), "rank 0 should have removed the id file once the communicator was up"
+    dist.barrier()
+    print(f"multigpu_check OK: rank {rank}/{world}, units 7 (uneven) and 16, torch + native all-gather, tables bit-identical")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

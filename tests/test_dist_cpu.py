@@ -140,3 +140,62 @@ def test_burst_map_and_phase_frames():
     assert len(m2) == 6 and np.all(np.isnan(m2[:5])) and m2[5] == 0
     assert gd.burst_map(np.array([[-1.0, -1.0]])).size == 0
     assert list(gd.sampling_phase_frames(pi, pi[:2] + [3.0, 0], 8)) == [1.0, 2.0]
+
+
+def _exchange(lib, path, nonce, world, rank, ident, timeout):
+    import ctypes as C
+    buf = C.create_string_buffer(ident, 128)
+    rc = lib.gsmcal_comm_id_file_exchange(str(path).encode(), nonce, world, rank, buf, timeout)
+    return rc, buf.raw
+
+
+@pytest.mark.parametrize("nonce", [0x1234ABCD5678, 0])
+def test_id_file_bootstrap_ignores_a_stale_file(tmp_path, nonce):
+    """ADVICE r2 (gsmcal_comm_init_file): a file left at the path by an earlier run must not be taken for this run's id.
+    Two ranks (threads; the C call releases the GIL), the reader starts first with a stale record already in place -- a
+    record of the old format, one with another nonce, and (nonce 0) one whose age is beyond the stale window."""
+    import struct
+    import threading
+    import time
+
+    import gsmcal
+    lib = gsmcal.load()
+    path = tmp_path / "rccl_id"
+    stale_id = bytes([0xEE]) * 128
+    fresh_id = bytes(range(128))
+    if nonce:
+        path.write_bytes(struct.pack("<QQ", 0x3144494C41434D47, nonce ^ 1) + stale_id)      # right format, another launch
+    else:
+        path.write_bytes(struct.pack("<QQ", 0x3144494C41434D47, 0) + stale_id)
+        old = time.time() - 3600.0
+        os.utime(path, (old, old))                                                          # an hour old: beyond the window
+    got = {}
+
+    def reader():
+        got["r"] = _exchange(lib, path, nonce, 2, 1, bytes(128), 20.0)
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.5)                                         # the reader has been polling the stale file for a while
+    assert t.is_alive(), "the reader accepted a stale id file"
+    rc0, _ = _exchange(lib, path, nonce, 2, 0, fresh_id, 20.0)
+    t.join(timeout=30)
+    assert rc0 == 0 and got["r"][0] == 0
+    assert got["r"][1] == fresh_id
+    # rank 0's clean-up after ncclCommInitRank: nothing is left for the next launch to trip over
+    assert lib.gsmcal_comm_id_file_remove(str(path).encode()) == 0 and not path.exists()
+    # a bare 128-byte file (the round-2 format) is never accepted, and a reader without a writer times out
+    path.write_bytes(stale_id)
+    rc, _ = _exchange(lib, path, nonce, 2, 1, bytes(128), 0.3)
+    assert rc < 0
+
+
+def test_plain_bench_gpus_n_starts_its_own_ranks_and_fails_clearly_without_the_devices():
+    """`python bench.py --gpus N` (no launcher) must start N ranks itself; on a node with fewer devices
+    every rank says so and the command exits non-zero -- after spawning, not on a launcher check."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "RANK"})
+    assert p.returncode != 0
+    assert p.stderr.count("--gpus 2 needs 2 devices") >= 2, p.stderr[-2000:]      # both children got as far as counting devices
+    assert "must be launched with" not in p.stderr

@@ -11,8 +11,9 @@ class FakeRtlTcp(threading.Thread):
     """Minimal rtl_tcp: sends the 12-byte greeting, then an endless counter-patterned IQ byte stream in small,
     irregular pieces; collects the 5-byte command packets it receives."""
 
-    def __init__(self, stall_after=None):
+    def __init__(self, stall_after=None, exact=False):
         super().__init__(daemon=True)
+        self.exact = exact                       # stop at exactly stall_after stream bytes (else: after the piece crossing it)
         self.srv = socket.socket()
         self.srv.bind(("127.0.0.1", 0))
         self.srv.listen(1)
@@ -41,6 +42,8 @@ class FakeRtlTcp(threading.Thread):
                     self.stop.wait(0.05)
                     continue
                 n = int(rng.integers(1, 70000))
+                if self.exact and self.stall_after is not None:
+                    n = min(n, self.stall_after - sent)
                 conn.sendall(self.stream_bytes(n, sent).tobytes())
                 sent += n
         except (BrokenPipeError, ConnectionResetError, OSError):
@@ -102,6 +105,61 @@ def test_short_read_is_retried_then_reported(gsmcal_mod):
         buf = np.zeros(n2, dtype=np.uint8)
         with pytest.raises(IOError):                                  # :99-100 -- the reference loops forever; the mirror gives up loudly
             ing.capture_all([d], [memoryview(buf)], max_tries=2)
+    finally:
+        d.close()
+        srv.stop.set()
+        srv.join(2.0)
+
+
+def test_read_timeout_bounds_the_whole_read_and_pairing_survives_an_odd_short_read(gsmcal_mod):
+    """(1) MATLAB's Timeout=1 bounds the whole fread (gsm_sync_demod.m:64) -- a peer that trickles must not
+    hold a capture beyond the timeout; (2) a short read of an odd number of bytes must not swap I and Q of every later
+    capture."""
+    import time
+    ing = gsmcal_mod.ingest
+    a, b = socket.socketpair()
+    try:
+        stop = threading.Event()
+
+        def trickle():                                    # one byte every 50 ms: each recv succeeds well inside the timeout
+            i = 0
+            while not stop.is_set() and i < 200:
+                try:
+                    b.sendall(bytes([i & 0xFF]))
+                except OSError:
+                    return
+                i += 1
+                time.sleep(0.05)
+
+        t = threading.Thread(target=trickle, daemon=True)
+        t.start()
+        view = memoryview(bytearray(1000))
+        t0 = time.monotonic()
+        got = ing.read_exact(a, view, timeout=0.4)
+        dt = time.monotonic() - t0
+        stop.set()
+        t.join(2.0)
+        assert 0 < got < 1000 and dt < 1.0, (got, dt)     # round 2: every recv re-armed the timeout and this took 50 s
+    finally:
+        a.close(); b.close()
+
+    srv = FakeRtlTcp(stall_after=101, exact=True)         # an ODD number of stream bytes after the greeting, then silence
+    srv.start()
+    d = ing.RtlTcpDongle("127.0.0.1", srv.port, timeout=0.2)
+    try:
+        time.sleep(0.3)
+        assert d.flush(12) == 12                          # the greeting (kept even so the stream itself starts on an I byte)
+        d.parity = 0
+        buf = np.zeros(200, dtype=np.uint8)
+        got = d.capture_into(memoryview(buf))
+        assert got < 200 and got % 2 == 1 and d.parity == 1
+        srv.stall_after = None                            # the stream resumes
+        buf2 = np.zeros(4000, dtype=np.uint8)
+        got2 = d.capture_into(memoryview(buf2))
+        assert got2 == 4000 and d.parity == 0
+        # one byte was dropped to get back onto an I boundary: the capture starts at an even stream offset
+        first = got + 1
+        assert first % 2 == 0 and np.array_equal(buf2, FakeRtlTcp.stream_bytes(4000, first))
     finally:
         d.close()
         srv.stop.set()
