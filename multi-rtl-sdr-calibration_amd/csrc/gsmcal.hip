@@ -51,7 +51,7 @@ struct ProfRec {
 #define MAX_LANES 16
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr;
+    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
@@ -97,6 +97,7 @@ struct gsmcal_ctx {
     double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
     bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
+    bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     gsmcal_params params;           // thresholds (defaults = the reference's literals)
@@ -273,6 +274,7 @@ size_t fused_lds(const Source& src, int level, int len, size_t scratch) {
 int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, bool tiles, int nwin_grid,
                   cplx* dst, long dst_stream_stride, long dst_win_stride) {
     GatherArgs a;
+    memset(&a, 0, sizeof(a));          // (l0 = nullptr: a stand-alone gather never reads the fine search's window buffer)
     a.src_kind = src.kind; a.level = level; a.len = len; a.tiles = tiles ? 1 : 0; a.ntaps = src.ntaps; a.pad = 0;
     a.raw = src.raw; a.raw_stride = src.raw_stride; a.arr = src.arr; a.arr_stride = src.arr_stride;
     a.coef = src.coef; a.dst = dst; a.dst_stream_stride = dst_stream_stride; a.dst_win_stride = dst_win_stride;
@@ -292,8 +294,10 @@ int ensure_twiddles(gsmcal_ctx* c, int nfft) {
     return 0;
 }
 
-size_t burst_scratch(const Geom& g) {   // w37 (40) | wN2 | P[2*hnl <= nfft/4]   (B lives in the free gather buffer)
-    return ((size_t)40 + g.nfft / 37 + 16 + g.nfft / 16 + 2) * sizeof(cplx) + (size_t)(g.nfft / 4) * sizeof(double);
+size_t burst_scratch(const Geom& g) {   // w37 (40) | wN2 | P region: the SNR gate's rotator tables pw[16] | base[nfft/16 + 1], later P[2*hnl] in their place
+    const size_t rot = ((size_t)16 + g.nfft / 16 + 2) * sizeof(cplx);
+    const size_t pw = (size_t)2 * 56 * sizeof(double);      // hnl = ceil(148 * 200e3 / symbol_rate / 2) = 55 for every oversampling ratio
+    return ((size_t)40 + g.nfft / 37) * sizeof(cplx) + (rot > pw ? rot : pw);
 }
 
 size_t fft_lds(const Geom& g) {   // xs | B[37][N2+1] | w37 (40) | wN2
@@ -335,8 +339,12 @@ StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
 // ---- FCCH_fine_correction body (input at level lvl; creates levels lvl+1 (lerp), lvl+2 (mix)) ----
 // setup_done: the window setup already ran at the end of k_coarse_scan (batch path).
 // next_sch_lvl >= 0: also run SCH_corr_rate_correction's window setup in the last decision launch.
+// chain != nullptr (batch path): everything behind the chunk sweep -- k_fine_verify and the three per-burst stages of
+// FCCH_fine_correction / SCH_corr_rate_correction / carrier_correct_post_SCH -- goes out as ONE k_post_chain launch; the
+// caller then skips run_sch / run_post.  *chain is set to false where the geometry does not allow it.
+struct ChainOut { double* table; double* pos_info_out; long* r_len_out; bool fused; };
 int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int H, bool setup_done,
-             int next_sch_lvl, int len_ts) {
+             int next_sch_lvl, int len_ts, ChainOut* chain = nullptr) {
     StreamState* st = (StreamState*)c->cur->state.p;
     const long wstride = g.fine_wlen, sstride = (long)H * g.fine_wlen;
     RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
@@ -399,6 +407,48 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
         const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) + 15) & ~(size_t)15;
         sa_fine.NB = 1;
+        if (chain) {
+            // ---- the fused tail of the chain: verify -> bursts -> SCH windows -> post-SCH bursts in one launch ----
+            const int wl_sch = g.sch_nshift - 1 + len_ts;
+            const size_t sch_scratch = (size_t)(len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+            size_t lds = vlds;
+            lds = std::max(lds, fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)));
+            lds = std::max(lds, fused_lds(src, lvl + 2, wl_sch, sch_scratch));
+            lds = std::max(lds, fused_lds(src, lvl + 3, g.nfft, burst_scratch(g)));
+            lds = std::max(lds, (sizeof(StreamState) + 15) & ~(size_t)15);
+            // only while every workgroup of the launch is resident at once (three 512-thread workgroups per CU): a workgroup
+            // waiting at a stream barrier holds its slot, which costs nothing in the latency regime (64 streams: 0.234 vs
+            // 0.237 ms per step) and a fifth of the throughput beyond it (256 streams: 0.73 vs 0.63 ms; 1024: 2.53 vs 2.13)
+            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && lds <= 53 * 1024 &&
+                           (long)H * S <= 3L * c->n_cu;
+            if (chain->fused) {
+                const size_t need = (size_t)2 * S * sizeof(unsigned);
+                if (c->cur->postctr.cap < need) {
+                    RET_IF(ensure(c, c->cur->postctr, need));
+                    HIPCHK(c, hipMemsetAsync(c->cur->postctr.p, 0, c->cur->postctr.cap, c->cur->stream));
+                }
+                PostChainArgs pa;
+                memset(&pa, 0, sizeof(pa));
+                pa.ga1 = gather_args(src, lvl + 1, g.nfft);
+                pa.ga_sch = gather_args(src, lvl + 2, wl_sch);
+                pa.ga0 = gather_args(src, lvl + 3, g.nfft);
+                if (c->cur->win_l0_len > 0) {
+                    for (GatherArgs* ga : {&pa.ga1, &pa.ga0}) { ga->l0 = win; ga->l0_stream_stride = sstride; ga->l0_win_stride = wstride; ga->l0_len = c->cur->win_l0_len; }
+                }
+                pa.sa = sa_fine;
+                pa.sa.table = chain->table; pa.sa.pos_info_out = chain->pos_info_out; pa.sa.r_len_out = chain->r_len_out;
+                pa.ctr = (unsigned*)c->cur->postctr.p; pa.gen = pa.ctr + S;
+                pa.lvl_fine = lvl; pa.lvl_sch = lvl + 2; pa.lvl_post = lvl + 3;
+                pa.nfft = g.nfft; pa.ov = g.ov; pa.len_ts = len_ts; pa.sch_nshift = g.sch_nshift; pa.fine_nshift = g.fine_nshift; pa.H = H;
+                pa.tw_g = (const cplx*)c->tw.p; pa.ts = (const cplx*)c->ts.p;
+                pa.win = win; pa.win_stream_stride = sstride; pa.win_stride = wstride;
+                pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
+                pa.with_totals = chain->table ? 1 : 0;
+                LAUNCH(c, k_post_chain, dim3(H, S), dim3(PC_THREADS), lds, st, pa);
+                CHECK_LAUNCH(c);
+                return 0;
+            }
+        }
         TailArgs tl;
         RET_IF(make_tail(c, S, sa_fine, STEP_FINE_DECIDE, lvl, 0, tl));
         LAUNCH(c, k_fine_verify, dim3(H, S), dim3(FV_THREADS), vlds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
@@ -868,6 +918,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_post_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_equalise, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_fd_training, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -895,6 +946,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (sse) c->snr_screen_db = atof(sse);
     const char* fge = getenv("GSMCAL_FUSE_GATHER");
     if (fge) c->fuse_fine_gather = atoi(fge) != 0;
+    const char* fpe = getenv("GSMCAL_FUSE_POST");
+    if (fpe) c->fuse_post = atoi(fpe) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
@@ -931,7 +984,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.postctr};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1511,11 +1564,13 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));         // :117 (+ state init, fine setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;
-        RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts));                              // :118 (+ SCH window setup)
-        RET_IF(run_sch(c, S, src, 2, g, H, len_ts, true, 3));                               // :119 (+ post-SCH window setup)
-        RET_IF(run_post(c, S, src, 3, g, H, true, d_table + (size_t)lo * GSMCAL_TABLE_COLS,
-                        d_pos_info ? d_pos_info + (size_t)lo * 2 * MAXROWS : nullptr,
-                        d_r_len ? d_r_len + lo : nullptr));                                 // :120, :123-124
+        ChainOut co{d_table + (size_t)lo * GSMCAL_TABLE_COLS, d_pos_info ? d_pos_info + (size_t)lo * 2 * MAXROWS : nullptr,
+                    d_r_len ? d_r_len + lo : nullptr, false};
+        RET_IF(run_fine(c, S, src, 0, g, H, true, 2, len_ts, &co));                         // :118 (+ SCH window setup; fused: :118-124)
+        if (!co.fused) {
+            RET_IF(run_sch(c, S, src, 2, g, H, len_ts, true, 3));                           // :119 (+ post-SCH window setup)
+            RET_IF(run_post(c, S, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out));   // :120, :123-124
+        }
         if (d_r_correct) {
             StreamTileArgs ta;
             ta.raw = raw_i; ta.raw_stride = 2 * n; ta.coef = (const double*)c->coef.p; ta.ntaps = ntaps;
@@ -1857,7 +1912,7 @@ int gsmcal_devtiming_begin(gsmcal_ctx* c) {
 }
 int gsmcal_devtiming_report(gsmcal_ctx* c) {
     if (!c || !g_stamp_buf) return GSMCAL_E_ARG;
-    static const char* names[KID_N] = {"coarse_snr", "coarse_scan", "gather", "cert", "chunk", "verify", "burst_tone<1>", "window_sch", "burst_tone<0>", "front"};
+    static const char* names[KID_N] = {"coarse_snr", "coarse_scan", "gather|post_chain barriers", "cert", "chunk", "verify", "burst_tone<1>", "window_sch", "burst_tone<0>", "front"};
     HIPCHK(c, hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)KID_N * DEV_STAMP_BLOCKS * 16);
     HIPCHK(c, hipMemcpy(h.data(), g_stamp_buf, h.size() * 8, hipMemcpyDeviceToHost));

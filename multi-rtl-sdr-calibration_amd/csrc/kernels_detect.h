@@ -1400,6 +1400,7 @@ __device__ __forceinline__ void peak_store(PeakOut* dst, const PeakOut& o) {
     __hip_atomic_store(d + 1, (unsigned long long)(unsigned)o.tie | ((unsigned long long)(unsigned)o.k << 32), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+template <int FVT>
 __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__ sts,
                                                  const cplx* __restrict__ win, long win_stream_stride,
                                                  long win_stride, int nshift, int nfft,
@@ -1413,8 +1414,8 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     cplx* anchor = xs + wlen;                             // X_k at the chunk's first shift, per item
     int* items = (int*)(anchor + FV_MAX_ITEMS);           // (k << 8) | chunk
     __shared__ int n_items, n_over;
-    __shared__ double red_p[FV_THREADS / 64];
-    __shared__ int red_t[FV_THREADS / 64], red_k[FV_THREADS / 64];
+    __shared__ double red_p[FVT / 64];
+    __shared__ int red_t[FVT / 64], red_k[FVT / 64];
     const int s = blockIdx.y, w = blockIdx.x;
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1435,7 +1436,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     {
         const uint4* src = (const uint4*)(rec + ((size_t)s * H + w) * nchunk);
         uint4* dst = (uint4*)r;
-        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += FV_THREADS) dst[i] = src[i];
+        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += FVT) dst[i] = src[i];
     }
     if (tid == 0) { n_items = 0; n_over = 0; }
     __syncthreads();
@@ -1446,7 +1447,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
         if (v > L) L = v;
     }
     L *= 1.0 - 1e-9;
-    for (int i = tid; i < nopen * FK_CAP; i += FV_THREADS) {     // listed candidates of all open chunks
+    for (int i = tid; i < nopen * FK_CAP; i += FVT) {     // listed candidates of all open chunks
         const int c = i / FK_CAP, q = i - c * FK_CAP;
         const int cnt = r[c].count;
         if (cnt < 0) { if (q == 0) atomicAdd(&n_over, 1); continue; }
@@ -1469,7 +1470,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     int bt = 0x7fffffff, bk = 0x7fffffff;
     if (tid == 0 && fc.p > 0.0) { best = fc.p; bt = fc.t; bk = fc.k; }   // the certificate's bins compete with the rest
     if (n_items > 0 || slow) {
-        for (int i = tid; i < wlen; i += FV_THREADS) xs[i] = x[i];
+        for (int i = tid; i < wlen; i += FVT) xs[i] = x[i];
         __syncthreads();
         // normal case: one round over the listed items.  slow case: every (bin, open chunk) pair, FV_MAX_ITEMS at a time
         const long total = slow ? (long)nopen * nfft : (long)n_items;
@@ -1477,7 +1478,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
             const int ni = (int)(total - base < FV_MAX_ITEMS ? total - base : FV_MAX_ITEMS);
             if (slow) {
                 __syncthreads();
-                for (int i = tid; i < ni; i += FV_THREADS) {
+                for (int i = tid; i < ni; i += FVT) {
                     const long g = base + i;
                     items[i] = ((int)(g % nfft) << 8) | (int)(g / nfft);
                 }
@@ -1487,7 +1488,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
             // shifts of the chunk at once.  Unrolling the recurrence, X_k(t0+m) = W^(-km) [X_k(t0) + S_m] with
             // S_m = sum_{q<m} W^(kq) d_q, d_q = x[t0+q+nfft] - x[t0+q] (W = exp(-2 pi i/nfft)): a wave-wide prefix sum, and
             // the rotation drops out of the power |X_k(t0) + S_m|^2.
-            for (int i = wave; i < ni; i += FV_THREADS / 64) {
+            for (int i = wave; i < ni; i += FVT / 64) {
                 const int k = items[i] >> 8, c = items[i] & 0xFF;
                 const int t0 = c * FS_CHUNK;
                 const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
@@ -1529,7 +1530,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     if (lane == 0) { red_p[wave] = best; red_t[wave] = bt; red_k[wave] = bk; }
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < FV_THREADS / 64; ++i)
+        for (int i = 1; i < FVT / 64; ++i)
             if (red_p[i] > best || (red_p[i] == best && (red_t[i] < bt || (red_t[i] == bt && red_k[i] < bk)))) {
                 best = red_p[i]; bt = red_t[i]; bk = red_k[i];
             }
@@ -1689,35 +1690,9 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                 pre = raw_chunk(first + per, ncnt + ntp - 1, first_al);
             }
             for (int i0 = 4 * tid; i0 < cnt; i0 += 4 * nthr) {
-                double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
-                cplx w0 = xq[xs_pad(i0)], w1 = xq[xs_pad(i0 + 1)], w2 = xq[xs_pad(i0 + 2)], w3 = xq[xs_pad(i0 + 3)];
-#define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
-                ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);         \
-                ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
-                ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
-                ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
-                int t = 0;
-                for (; t + 4 <= ntp; t += 4) {        // gather_core's loop: every accumulator takes its taps oldest first
-                    const cplx* nx = xq + xs_pad(i0 + t + 4);
-                    const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
-                    const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
-                    GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
-                    GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
-                    GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
-                    GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
-                    w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
-                }
-                int p = i0 + t + 3;
-                for (; t < ntp; ++t) {
-                    const double c = c_s[ntp - 1 - t];
-                    GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
-                    w0 = w1; w1 = w2; w2 = w3;
-                    ++p;
-                    w3 = xq[xs_pad(p)];
-                }
-#undef GSMCAL_FIR_TAP
-                const cplx y0 = make_double2(ar0, ai0), y1 = make_double2(ar1, ai1), y2 = make_double2(ar2, ai2),
-                           y3 = make_double2(ar3, ai3);
+                cplx y0, y1, y2, y3;              // gather_core's loop: every accumulator takes its taps oldest first
+                if (ntp == 47) fir4_lds<47>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+                else fir4_lds<0>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
                 const int o = o0 + i0;
                 xs[FC_XP(o)] = y0; wout[o] = y0;
                 if (i0 + 1 < cnt) { xs[FC_XP(o + 1)] = y1; wout[o + 1] = y1; }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         e = wave_sum(e);
         if ((tid & 63) == 0) red[tid >> 6] = e;
         const int wave = tid >> 6, lane = tid & 63;
-        const int prior = prior_mode == 1 ? st->prior_bin[w] : nfft / 32;       // 37 for every oversampling ratio
+        const int prior = prior_mode == 1 ? st_i32(&st->prior_bin[w]) : nfft / 32;       // 37 for every oversampling ratio
         if (wave < 7) {
             int k = prior - 3 + wave;
             k = ((k % nfft) + nfft) % nfft;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
             if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
         }
         if (tid == 0) {
-            coherent_store(&st->sch_first[w], (double)(st->win_start[w] + 1 + mi));   // sp + max_idx - 1
+            coherent_store(&st->sch_first[w], (double)(st_i64(&st->win_start[w]) + 1 + mi));   // sp + max_idx - 1
             if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
         }
     }
@@ -703,7 +703,7 @@ enum { STEP_FINE_SETUP = 1, STEP_FINE_DECIDE = 2, STEP_CARRIER_DECIDE = 4, STEP_
 // `steps` is a bit set executed in the order of the enum; lvl_a / lvl_b: input level of the first /
 // second step of a merged pair (e.g. carrier_decide works on the fine stage's level, sch_setup on the
 // SCH stage's input level).  Called by every thread of a workgroup (>= 64 threads); `sh` is an LDS copy of the state.
-template <bool COHERENT>
+template <bool COHERENT, bool WT_STORE = false>
 __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const StepArgs& a, int steps, int lvl_a,
                                           int lvl_b, int s, StreamState* sh, int kid = -1) {
     const int lane = threadIdx.x;
@@ -740,7 +740,15 @@ __device__ __forceinline__ void step_body(StreamState* __restrict__ sts, const S
     }
     __syncthreads();
     TAIL_STAMP(11);
-    if (!(steps == STEP_TOTALS || steps == STEP_SCAN_ACCEPT) && lane < 64) StateLds::store(sts + s, sh, lane);
+    if (WT_STORE) {
+        // other workgroups of THIS launch read the state next (k_post_chain): write-through stores by the whole workgroup
+        // (one or two words per thread), every storing wave drains its own before the caller raises the stream's flag
+        const unsigned long long* src = (const unsigned long long*)sh;
+        unsigned long long* dst = (unsigned long long*)(sts + s);
+        for (int i = lane; i < (int)(sizeof(StreamState) / 8); i += blockDim.x)
+            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(steps == STEP_TOTALS || steps == STEP_SCAN_ACCEPT) && lane < 64) StateLds::store(sts + s, sh, lane);
     TAIL_STAMP(12);
 #undef TAIL_STAMP
 }
@@ -809,8 +817,105 @@ __global__ void __launch_bounds__(FV_THREADS) k_fine_verify(const StreamState* _
                                                      StreamState* __restrict__ sts_rw, TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    fine_verify_body(sts, win, win_stream_stride, win_stride, nshift, nfft, tw_g, rec, out, H, cert, n_open, smem);
+    fine_verify_body<FV_THREADS>(sts, win, win_stream_stride, win_stride, nshift, nfft, tw_g, rec, out, H, cert, n_open, smem);
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 1);
     stream_tail(sts_rw, tail, smem, KID_VERIFY);
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_post_chain: everything behind the fine search's chunk sweep in ONE launch -- the exact last word of the fine search
+// (fine_verify_body) and the three per-burst stages (k_burst_tone<1> -> k_window_sch -> k_burst_tone<0>) with the
+// reference's decision steps between them.  grid (H, S), block 512: workgroup (w, s) handles window w of stream s in every
+// stage.  The stages of one stream are separated by a PER-STREAM barrier instead of a kernel boundary: every workgroup of
+// the stream arrives on the stream's counter; the last one to arrive runs the decision step (on the state read past the
+// caches, written back write-through and drained) and raises the stream's generation word; the others poll it (one lane,
+// relaxed agent-scope loads, s_sleep).  No release / acquire fence anywhere: every word that crosses workgroups inside the
+// launch travels by write-through stores and L1-bypassing loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1
+// stores + sc1 loads both sides), so the eight L2s are neither written back nor invalidated.  What it saves over four
+// launches: streams no longer wait for the slowest workgroup of the whole grid at every stage, and the launch ramps.
+// Forward progress: a waiting workgroup waits only for workgroups of its own stream, which sit next to it in dispatch
+// order (blockIdx.y = stream), so with in-order dispatch the earliest unfinished stream always has (or is next to get) all
+// its workgroups resident, for any grid size.  A poll that runs out (never observed) marks the stream GSMCAL_E_HIP instead
+// of hanging the queue.
+// ------------------------------------------------------------------------------------------------
+#define PC_THREADS 512
+struct PostChainArgs {
+    GatherArgs ga1, ga_sch, ga0;       // burst windows at level lvl+1, SCH search windows, post-SCH burst windows
+    StepArgs sa;                       // one set of step arguments serves every decision step (NB = 1)
+    unsigned* ctr;                     // per stream: arrivals (monotonic inside the launch, re-armed by the last tail)
+    unsigned* gen;                     // per stream: stages whose decision step is complete
+    int lvl_fine, lvl_sch, lvl_post;   // input levels of the three reference functions
+    int nfft, ov, len_ts, sch_nshift, fine_nshift, H;
+    const cplx* tw_g; const cplx* ts;
+    const cplx* win; long win_stream_stride, win_stride;
+    const ChunkRec* rec; const FineCert* cert; PeakOut* peaks; int* n_open;
+    int with_totals, pad;
+};
+
+// barrier of stream blockIdx.y after stage `stage` (0-based) + the stream's decision `steps`, run by the last arriver
+__device__ __forceinline__ void stream_stage_barrier(StreamState* __restrict__ sts, const PostChainArgs& a, int stage, int steps,
+                                                     int lvl_a, int lvl_b, unsigned char* smem) {
+    __shared__ int sh_last;
+    const int s = blockIdx.y;
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1 + 3 * stage);      // (development build: arrival, decision done, released)
+    // this workgroup's hand-over values were stored write-through; every wave waits until its own are acknowledged
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(&a.ctr[s], 1u);           // relaxed, agent scope
+        sh_last = old == (unsigned)(gridDim.x * (stage + 1) - 1);
+    }
+    __syncthreads();
+    if (sh_last) {                                               // block-uniform
+        step_body<true, true>(sts, a.sa, steps, lvl_a, lvl_b, s, (StreamState*)smem);
+        __syncthreads();
+        DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 2 + 3 * stage);
+        if (threadIdx.x == 0) __hip_atomic_store(&a.gen[s], (unsigned)(stage + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(&a.gen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(stage + 1)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 40000000L) {                           // ~ seconds: a peer never came (not observed); fail, do not hang
+                atomicMin(&sts[s].status, GSMCAL_E_HIP);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 3 + 3 * stage);
+}
+
+__global__ void __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_post_chain(StreamState* __restrict__ sts, PostChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    // stage 0: FCCH_fine_correction.m:48-52, exact last word per window -> FINE_DECIDE (:52-137)
+    fine_verify_body<PC_THREADS>(sts, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
+                                 a.cert, a.n_open, smem);
+    stream_stage_barrier(sts, a, 0, STEP_FINE_DECIDE, a.lvl_fine, 0, smem);
+    // stage 1: bursts of the resampled stream (:141-165, :185-196) -> CARRIER_DECIDE + SCH window setup
+    burst_tone_body<1>(sts, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem);
+    stream_stage_barrier(sts, a, 1, STEP_CARRIER_DECIDE | STEP_SCH_SETUP, a.lvl_fine, a.lvl_sch, smem);
+    // stage 2: SCH_corr_rate_correction.m:45-55 -> SCH_DECIDE (:59-181) + post-SCH window setup
+    window_sch_body(sts, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem);
+    stream_stage_barrier(sts, a, 2, STEP_SCH_DECIDE | STEP_POST_SETUP, a.lvl_sch, a.lvl_post, smem);
+    // stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124)
+    burst_tone_body<0>(sts, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem);
+    {
+        __shared__ int sh_fin;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(&a.ctr[blockIdx.y], 1u);
+            sh_fin = old == (unsigned)(gridDim.x * 4 - 1);
+            if (sh_fin) {                                        // every workgroup of the stream is past its last poll: re-arm
+                atomicExch(&a.ctr[blockIdx.y], 0u);
+                __hip_atomic_store(&a.gen[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (sh_fin) step_body<true>(sts, a.sa, a.with_totals ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, a.lvl_post, 0,
+                                    blockIdx.y, (StreamState*)smem);
+    }
 }

@@ -585,6 +585,14 @@ struct GatherArgs {
     const cplx* l0; long l0_stream_stride, l0_win_stride; int l0_len, pad2;
 };
 
+// State fields read past the vector L1 (relaxed agent-scope loads = `sc1`): what a workgroup needs when ANOTHER workgroup
+// of the same launch may have rewritten the field (k_post_chain's in-launch decision steps).
+__device__ __forceinline__ int st_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long st_i64(const long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double st_f64(const double* p) {
+    return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 __device__ __forceinline__ long level_len(const StreamState* st, int level) {
     return level == 0 ? st->n0 : st->op[level].n;
 }
@@ -592,6 +600,52 @@ __device__ __forceinline__ long level_len(const StreamState* st, int level) {
 // LDS position of staged input sample p: one 16-byte pad after every 4 samples, so that lanes reading
 // samples 4 apart (the 4-outputs-per-lane FIR below) hit distinct banks with ds_read_b128.
 __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
+
+// ------------------------------------------------------------------------------------------------
+// filter(coef,1,.) for FOUR consecutive outputs i0 .. i0+3 from the padded LDS copy xq (xs_pad indexing; i0 a multiple of
+// 4): y[i] = sum_k coef[k] x[i-k], every accumulator taking its taps oldest first (transposed direct-form order) -- the
+// one FIR loop of gather_core and of k_fine_cert's fused window build, so both give bit-identical level-0 samples.
+// NTP > 0: the tap count is a compile-time constant (the production fir1(46) filter): two trips per iteration with known
+// bounds, so the LDS reads of a trip are issued under the FMAs of the one before.  (Unrolled completely the compiler hoists
+// every coefficient and sample load: 256 registers and scratch.)
+// ------------------------------------------------------------------------------------------------
+template <int NTP>
+__device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const double* __restrict__ c_s, int i0, int ntp_rt,
+                                         cplx* y0, cplx* y1, cplx* y2, cplx* y3) {
+    const int ntp = NTP > 0 ? NTP : ntp_rt;
+    double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
+    cplx w0 = xq[xs_pad(i0)], w1 = xq[xs_pad(i0 + 1)], w2 = xq[xs_pad(i0 + 2)], w3 = xq[xs_pad(i0 + 3)];
+#define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
+    ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);                     \
+    ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);                     \
+    ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);                     \
+    ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
+    // four taps per trip: the next four samples are one aligned, contiguous 64-byte group (i0 is a multiple of 4),
+    // fetched together.  Every accumulator still takes its taps in the same order (oldest first), so the sums are
+    // bit-identical to a one-tap loop.
+    int t = 0;
+#pragma unroll 2
+    for (; t + 4 <= ntp; t += 4) {
+        const cplx* nx = xq + xs_pad(i0 + t + 4);
+        const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
+        const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
+        GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
+        GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
+        GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
+        GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
+        w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
+    }
+    int p = i0 + t + 3;
+    for (; t < ntp; ++t) {
+        const double c = c_s[ntp - 1 - t];
+        GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
+        w0 = w1; w1 = w2; w2 = w3;
+        ++p;
+        w3 = xq[xs_pad(p)];
+    }
+#undef GSMCAL_FIR_TAP
+    *y0 = make_double2(ar0, ai0); *y1 = make_double2(ar1, ai1); *y2 = make_double2(ar2, ai2); *y3 = make_double2(ar3, ai3);
+}
 
 // LDS layout of gather_core (byte offsets from the dynamic LDS base); also used by the host to size launches.
 struct GatherCarve {
@@ -653,16 +707,18 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     if (a.src_kind != SRC_ARR && NT > 64 && tid >= 64)
         for (int i = tid - 64; i < a.ntaps; i += NT - 64) c_s[i] = a.coef[i];
     if (tid < 64) {
-        const int pre_nwin = st->n_win;
-        const long pre_n0 = st->n0;
-        const long pre_ws = (!a.tiles && widx >= 0 && widx < MAXH) ? st->win_start[widx] : 0;
-        const double pre_mr = st->mean_re, pre_mi = st->mean_im;
+        // (loads that bypass the vector L1: inside a fused launch these fields were rewritten by another workgroup's
+        // decision step -- write-through stores -- since this CU may last have read them; L2-served, same cost as plain)
+        const int pre_nwin = st_i32(&st->n_win);
+        const long pre_n0 = st_i64(&st->n0);
+        const long pre_ws = (!a.tiles && widx >= 0 && widx < MAXH) ? st_i64(&st->win_start[widx]) : 0;
+        const double pre_mr = st_f64(&st->mean_re), pre_mi = st_f64(&st->mean_im);
         int op_type[NLEVELS];
         double op_param[NLEVELS];
         long lvl_n[NLEVELS];
         lvl_n[0] = pre_n0; op_type[0] = OP_NONE; op_param[0] = 0.0;
 #pragma unroll
-        for (int j = 1; j < NLEVELS; ++j) { op_type[j] = st->op[j].type; op_param[j] = st->op[j].param; lvl_n[j] = st->op[j].n; }
+        for (int j = 1; j < NLEVELS; ++j) { op_type[j] = st_i32(&st->op[j].type); op_param[j] = st_f64(&st->op[j].param); lvl_n[j] = st_i64(&st->op[j].n); }
 #ifdef GSMCAL_DEVTIMING
         __builtin_amdgcn_s_waitcnt(0);
         GC_STAMP(14);
@@ -695,8 +751,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         int l0h = -1;
         long l0off = 0;
         if (a.l0 && a.src_kind == SRC_RAW && L > 0) {
-            const int nf = st->n_fine_ws;
-            const long fw = (tid < nf && tid < MAXH) ? st->fine_ws[tid] : 0;
+            const int nf = st_i32(&st->n_fine_ws);
+            const long fw = (tid < nf && tid < MAXH) ? st_i64(&st->fine_ws[tid]) : 0;
             const unsigned long long m = __ballot(tid < nf && tid < MAXH && fw <= clo && chi < fw + a.l0_len);
             if (m) {
                 l0h = __ffsll((long long)m) - 1;
@@ -764,40 +820,13 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         // filter(coef,1,.) : y[i] = sum_k coef[k] x[i-k], accumulated oldest tap first (transposed
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
-            double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
-            cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
-#define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
-                ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);         \
-                ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
-                ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
-                ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
-            // four taps per trip: the next four samples are one aligned, contiguous 64-byte group (i0 is a multiple
-            // of 4), fetched together, and the sliding window needs no register shuffling.  Every accumulator still
-            // takes its taps in the same order (oldest first), so the sums are bit-identical to the one-tap loop.
-            int t = 0;
-            for (; t + 4 <= ntp; t += 4) {
-                const cplx* nx = xs + xs_pad(i0 + t + 4);
-                const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
-                const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
-                GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
-                GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
-                GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
-                GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
-                w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
-            }
-            int p = i0 + t + 3;
-            for (; t < ntp; ++t) {
-                const double c = c_s[ntp - 1 - t];
-                GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
-                w0 = w1; w1 = w2; w2 = w3;
-                ++p;
-                w3 = xs[xs_pad(p)];
-            }
-#undef GSMCAL_FIR_TAP
-            out0[i0] = make_double2(ar0, ai0);
-            if (i0 + 1 < cnt0) out0[i0 + 1] = make_double2(ar1, ai1);
-            if (i0 + 2 < cnt0) out0[i0 + 2] = make_double2(ar2, ai2);
-            if (i0 + 3 < cnt0) out0[i0 + 3] = make_double2(ar3, ai3);
+            cplx y0, y1, y2, y3;
+            if (ntp == 47) fir4_lds<47>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            else fir4_lds<0>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            out0[i0] = y0;
+            if (i0 + 1 < cnt0) out0[i0 + 1] = y1;
+            if (i0 + 2 < cnt0) out0[i0 + 2] = y2;
+            if (i0 + 3 < cnt0) out0[i0 + 3] = y3;
         }
     }
     GC_STAMP(12);

@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--frames", type=int, default=102)
-    ap.add_argument("--distinct", type=int, default=16)
+    ap.add_argument("--distinct", type=int, default=64)
     ap.add_argument("--workload", default="calib")
     ap.add_argument("--mode", default="table")
     args = ap.parse_args()
