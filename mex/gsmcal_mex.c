@@ -17,7 +17,11 @@
  * with s the 2N x D uint8 matrix fread() delivers (gsm_sync_demod.m:96; pass uint8(s) if it was read as double).
  * tests/test_abi_cpu.py compiles every target against a declaration-only mex.h (tests/mex_stub) as a prototype check.
  *
- * -R2018a selects the interleaved-complex API, which matches the ABI's interleaved double[2].
+ * Both MEX complex-storage APIs are handled: with -R2018a (MX_HAS_INTERLEAVED_COMPLEX = 1) complex arrays
+ * are interleaved like the ABI's double[2] and are passed through without a copy; without the flag -- the only API of the
+ * MATLAB releases the reference was written for (README: Ubuntu 12.04, R2008b-era .fda files) and still the default of
+ * `mex` -- complex arrays are split (mxGetPr / mxGetPi) and the gateway interleaves inputs / de-interleaves outputs:
+ *     mex -DGSMCAL_FN_$f -output $f mex/gsmcal_mex.c -Iinclude -L... -lgsmcal          (split API, any release)
  * Argument lists, 1-based positions, row/column shapes and sentinels follow the .m files
  * (cited per function); negative ABI status codes become mexErrMsgIdAndTxt errors, positive ones
  * (reference sentinels) return normally with the sentinel outputs, as the .m files do.
@@ -46,46 +50,100 @@ static void chk(int rc, const char* what) {
     if (rc < 0) mexErrMsgIdAndTxt("gsmcal:error", "%s failed (%d): %s", what, rc, gsmcal_last_error(g_ctx));
 }
 
-static const double* cplx_in(const mxArray* a, mwSize* n) {   /* complex (or real, widened) vector -> interleaved */
+/* ---- the two complex-storage APIs behind one set of helpers ------------------------------------------------------ */
+#if defined(MX_HAS_INTERLEAVED_COMPLEX) && MX_HAS_INTERLEAVED_COMPLEX
+#define GSMCAL_INTERLEAVED 1
+#define REAL_PTR(a) mxGetDoubles(a)
+#define U8_PTR(a) ((const uint8_t*)mxGetUint8s(a))
+#else
+#define GSMCAL_INTERLEAVED 0
+#define REAL_PTR(a) mxGetPr(a)
+#define U8_PTR(a) ((const uint8_t*)mxGetData(a))
+#endif
+
+/* complex (or real, widened) array -> interleaved doubles; *n = number of elements.  Interleaved API: the array's own
+ * storage when it is complex.  Split API: always a copy (freed by MATLAB when the MEX call returns, like every mxCalloc). */
+static const double* cplx_in(const mxArray* a, mwSize* n) {
     *n = mxGetNumberOfElements(a);
+#if GSMCAL_INTERLEAVED
     if (mxIsComplex(a)) return (const double*)mxGetComplexDoubles(a);
+#endif
     {
-        double* t = (double*)mxCalloc(2 * (*n), sizeof(double));
-        const double* r = mxGetDoubles(a);
+        double* t = (double*)mxCalloc(2 * (*n) + 2, sizeof(double));
+        const double* re = REAL_PTR(a);
         mwSize i;
-        for (i = 0; i < *n; ++i) t[2 * i] = r[i];
+        for (i = 0; i < *n; ++i) t[2 * i] = re[i];
+#if !GSMCAL_INTERLEAVED
+        if (mxIsComplex(a)) {
+            const double* im = mxGetPi(a);
+            for (i = 0; i < *n; ++i) t[2 * i + 1] = im[i];
+        }
+#endif
         return t;
     }
 }
 
 static mxArray* scalar(double v) { return mxCreateDoubleScalar(v); }
 
-static mxArray* cplx_col(const double* data, mwSize n) {
-    mxArray* o = mxCreateDoubleMatrix(n, 1, mxCOMPLEX);
-    memcpy(mxGetComplexDoubles(o), data, 2 * n * sizeof(double));
-    return o;
+/* m x n complex output the ABI fills as interleaved doubles: cplx_out_begin() gives the buffer to hand to the ABI,
+ * cplx_out_end() the finished mxArray (interleaved API: the array's own storage, no copy; split API: de-interleaved) */
+typedef struct { mxArray* arr; double* buf; mwSize m, n; } cplx_out;
+static double* cplx_out_begin(cplx_out* o, mwSize m, mwSize n) {
+    o->m = m; o->n = n;
+#if GSMCAL_INTERLEAVED
+    o->arr = mxCreateDoubleMatrix(m, n, mxCOMPLEX);
+    o->buf = (double*)mxGetComplexDoubles(o->arr);
+#else
+    o->arr = NULL;
+    o->buf = (double*)mxMalloc((2 * m * n + 2) * sizeof(double));
+#endif
+    return o->buf;
+}
+static mxArray* cplx_out_end(cplx_out* o) {
+#if !GSMCAL_INTERLEAVED
+    mwSize i, tot = o->m * o->n;
+    double *re, *im;
+    o->arr = mxCreateDoubleMatrix(o->m, o->n, mxCOMPLEX);
+    re = mxGetPr(o->arr); im = mxGetPi(o->arr);
+    for (i = 0; i < tot; ++i) { re[i] = o->buf[2 * i]; im[i] = o->buf[2 * i + 1]; }
+    mxFree(o->buf);
+#endif
+    return o->arr;
+}
+
+static mxArray* cplx_col(const double* data, mwSize n) {   /* n x 1 complex column from interleaved doubles */
+    cplx_out o;
+    double* b = cplx_out_begin(&o, n, 1);
+    memcpy(b, data, 2 * n * sizeof(double));
+    return cplx_out_end(&o);
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #if defined(GSMCAL_FN_raw2iq)
     /* b = raw2iq(a)                                   raw2iq.m:5 */
     mwSize rows = mxGetM(prhs[0]), d = mxGetN(prhs[0]);
-    plhs[0] = mxCreateDoubleMatrix(rows / 2, d, mxCOMPLEX);
-    chk(gsmcal_raw2iq(ctx(), mxGetDoubles(prhs[0]), (long)rows, (int)d, (double*)mxGetComplexDoubles(plhs[0])), "raw2iq");
+    cplx_out o;
+    double* b = cplx_out_begin(&o, rows / 2, d);
+    chk(gsmcal_raw2iq(ctx(), REAL_PTR(prhs[0]), (long)rows, (int)d, b), "raw2iq");
+    plhs[0] = cplx_out_end(&o);
 
 #elif defined(GSMCAL_FN_chn_filter_8x_4x)
     /* r = chn_filter_8x_4x(s)                         chn_filter_8x_4x.m:5 */
     mwSize n = mxGetM(prhs[0]), d = mxGetN(prhs[0]), tot;
     const double* s = cplx_in(prhs[0], &tot);
-    plhs[0] = mxCreateDoubleMatrix((n + 1) / 2, d, mxCOMPLEX);
-    chk(gsmcal_chn_filter_8x_4x(ctx(), s, (long)n, (int)d, NULL, 0, (double*)mxGetComplexDoubles(plhs[0])), "chn_filter_8x_4x");
+    cplx_out o;
+    double* b = cplx_out_begin(&o, (n + 1) / 2, d);
+    chk(gsmcal_chn_filter_8x_4x(ctx(), s, (long)n, (int)d, NULL, 0, b), "chn_filter_8x_4x");
+    plhs[0] = cplx_out_end(&o);
 
 #elif defined(GSMCAL_FN_chn_filter_4x)
     /* r = chn_filter_4x(s)                            chn_filter_4x.m:5 */
     mwSize n = mxGetM(prhs[0]), d = mxGetN(prhs[0]), tot;
     const double* s = cplx_in(prhs[0], &tot);
-    plhs[0] = mxCreateDoubleMatrix(n, d, mxCOMPLEX);
-    chk(gsmcal_chn_filter_4x(ctx(), s, (long)n, (int)d, NULL, 0, (double*)mxGetComplexDoubles(plhs[0])), "chn_filter_4x");
+    cplx_out o;
+    double* b = cplx_out_begin(&o, n, d);
+    chk(gsmcal_chn_filter_4x(ctx(), s, (long)n, (int)d, NULL, 0, b), "chn_filter_4x");
+    plhs[0] = cplx_out_end(&o);
 
 #elif defined(GSMCAL_FN_move_fft_snr_runtime_avg)
     /* [hit_flag,hit_idx,hit_avg_snr,hit_snr] = move_fft_snr_runtime_avg(s,mv_len,fft_len,th) */
@@ -104,7 +162,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mwSize n;
     const double* s = cplx_in(prhs[0], &n);
     int hf; double hi, hs;
-    chk(gsmcal_specific_fft_snr_fix_avg(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetScalar(prhs[2]),
+    chk(gsmcal_specific_fft_snr_fix_avg(ctx(), s, (long)n, REAL_PTR(prhs[1]), (int)mxGetScalar(prhs[2]),
                                         mxGetScalar(prhs[3]), mxGetScalar(prhs[4]), &hf, &hi, &hs),
         "specific_fft_snr_fix_avg");
     plhs[0] = mxCreateLogicalScalar(hf != 0);
@@ -120,8 +178,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     chk(gsmcal_FCCH_coarse_position(ctx(), s, (long)n, (int)mxGetScalar(prhs[1]), pos, snr, GSMCAL_MAX_HITS, &cnt),
         "FCCH_coarse_position");
     plhs[0] = mxCreateDoubleMatrix(1, cnt, mxREAL);
-    memcpy(mxGetDoubles(plhs[0]), pos, cnt * sizeof(double));
-    if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, cnt, mxREAL); memcpy(mxGetDoubles(plhs[1]), snr, cnt * sizeof(double)); }
+    memcpy(REAL_PTR(plhs[0]), pos, cnt * sizeof(double));
+    if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, cnt, mxREAL); memcpy(REAL_PTR(plhs[1]), snr, cnt * sizeof(double)); }
 
 #elif defined(GSMCAL_FN_FCCH_fine_correction)
     /* [FCCH_pos,r,sampling_ppm,carrier_ppm] = FCCH_fine_correction(s,base_position,ov,carrier_freq) */
@@ -130,11 +188,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double pos[GSMCAL_MAX_HITS], sp, cp;
     int npos = 0; long lr = -1;
     double* r = (double*)mxMalloc(2 * n * sizeof(double));
-    chk(gsmcal_FCCH_fine_correction(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
+    chk(gsmcal_FCCH_fine_correction(ctx(), s, (long)n, REAL_PTR(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
                                     (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), pos, GSMCAL_MAX_HITS, &npos,
                                     r, (long)n, &lr, &sp, &cp), "FCCH_fine_correction");
     plhs[0] = mxCreateDoubleMatrix(1, npos, mxREAL);
-    memcpy(mxGetDoubles(plhs[0]), pos, npos * sizeof(double));
+    memcpy(REAL_PTR(plhs[0]), pos, npos * sizeof(double));
     if (nlhs > 1) plhs[1] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
     if (nlhs > 2) plhs[2] = scalar(sp);
     if (nlhs > 3) plhs[3] = scalar(cp);
@@ -148,13 +206,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double pi[2 * GSMCAL_MAX_POS_ROWS], sp;
     int rows = 0, i; long lr = -1;
     double* r = n ? (double*)mxMalloc(2 * n * sizeof(double)) : NULL;
-    chk(gsmcal_SCH_corr_rate_correction(ctx(), s, (long)n, mxGetDoubles(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
+    chk(gsmcal_SCH_corr_rate_correction(ctx(), s, (long)n, REAL_PTR(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
                                         ts, (int)nts, (int)mxGetScalar(prhs[3]), pi, GSMCAL_MAX_POS_ROWS, &rows,
                                         r, (long)n, &lr, &sp), "SCH_corr_rate_correction");
     plhs[0] = mxCreateDoubleMatrix(rows, 2, mxREAL);
     for (i = 0; i < rows; ++i) {
-        mxGetDoubles(plhs[0])[i] = pi[i];
-        mxGetDoubles(plhs[0])[rows + i] = pi[GSMCAL_MAX_POS_ROWS + i];
+        REAL_PTR(plhs[0])[i] = pi[i];
+        REAL_PTR(plhs[0])[rows + i] = pi[GSMCAL_MAX_POS_ROWS + i];
     }
     if (nlhs > 1) plhs[1] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
     if (nlhs > 2) plhs[2] = scalar(sp);
@@ -167,7 +225,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     int rows = (int)mxGetM(prhs[1]);
     double cp; long lr = -1;
     double* r = n ? (double*)mxMalloc(2 * n * sizeof(double)) : NULL;
-    chk(gsmcal_carrier_correct_post_SCH(ctx(), s, (long)n, mxGetDoubles(prhs[1]), rows, rows, (int)mxGetScalar(prhs[2]),
+    chk(gsmcal_carrier_correct_post_SCH(ctx(), s, (long)n, REAL_PTR(prhs[1]), rows, rows, (int)mxGetScalar(prhs[2]),
                                         mxGetScalar(prhs[3]), r, (long)n, &lr, &cp), "carrier_correct_post_SCH");
     plhs[0] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
     if (nlhs > 1) plhs[1] = scalar(cp);
@@ -176,7 +234,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #elif defined(GSMCAL_FN_total_ppm_calculation)
     /* ppm_out = total_ppm_calculation(ppm_in) */
     double out;
-    gsmcal_total_ppm_calculation(mxGetDoubles(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out);
+    gsmcal_total_ppm_calculation(REAL_PTR(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out);
     plhs[0] = scalar(out);
 #elif defined(GSMCAL_FN_gsmcal_calibrate)
     /* [table, pos_info] = gsmcal_calibrate(s, coef, sch_training_sequence, freq)      gsm_sync_demod.m:107-124 for all dongles
@@ -189,20 +247,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double* tab = (double*)mxMalloc(d * GSMCAL_TABLE_COLS * sizeof(double));
     double* pi = (double*)mxMalloc(d * 2 * GSMCAL_MAX_POS_ROWS * sizeof(double));
     if (!mxIsUint8(prhs[0])) mexErrMsgIdAndTxt("gsmcal:type", "s must be uint8 (the bytes fread(...,'uint8') delivers)");
-    for (i = 0; i < d; ++i) cf[i] = mxGetDoubles(prhs[3])[ncf == d ? i : 0];
-    chk(gsmcal_calibrate_batch(ctx(), (const uint8_t*)mxGetUint8s(prhs[0]), (int)d, (long)(rows2n / 2), mxGetDoubles(prhs[1]),
+    for (i = 0; i < d; ++i) cf[i] = REAL_PTR(prhs[3])[ncf == d ? i : 0];
+    chk(gsmcal_calibrate_batch(ctx(), U8_PTR(prhs[0]), (int)d, (long)(rows2n / 2), REAL_PTR(prhs[1]),
                                (int)mxGetNumberOfElements(prhs[1]), ts, (int)nts, cf, tab, pi, NULL, NULL), "gsmcal_calibrate");
     plhs[0] = mxCreateDoubleMatrix(d, GSMCAL_TABLE_COLS, mxREAL);
     for (i = 0; i < d; ++i)
-        for (k = 0; k < GSMCAL_TABLE_COLS; ++k) mxGetDoubles(plhs[0])[k * d + i] = tab[i * GSMCAL_TABLE_COLS + k];
+        for (k = 0; k < GSMCAL_TABLE_COLS; ++k) REAL_PTR(plhs[0])[k * d + i] = tab[i * GSMCAL_TABLE_COLS + k];
     if (nlhs > 1) {
         plhs[1] = mxCreateCellMatrix(1, d);
         for (i = 0; i < d; ++i) {
             const mwSize r = (mwSize)tab[i * GSMCAL_TABLE_COLS + GSMCAL_T_N_POS_ROWS];
             mxArray* m = mxCreateDoubleMatrix(r, 2, mxREAL);
             for (k = 0; k < r; ++k) {
-                mxGetDoubles(m)[k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + k];
-                mxGetDoubles(m)[r + k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + GSMCAL_MAX_POS_ROWS + k];
+                REAL_PTR(m)[k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + k];
+                REAL_PTR(m)[r + k] = pi[i * 2 * GSMCAL_MAX_POS_ROWS + GSMCAL_MAX_POS_ROWS + k];
             }
             mxSetCell(plhs[1], i, m);
         }
@@ -217,8 +275,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     plhs[0] = mxCreateDoubleMatrix(1, f, mxREAL);
     {
         mxArray* nh = mxCreateDoubleMatrix(1, f, mxREAL);
-        chk(gsmcal_fcch_scan_batch(ctx(), (const uint8_t*)mxGetUint8s(prhs[0]), (int)f, (long)(rows2n / 2), mxGetDoubles(prhs[1]),
-                                   (int)mxGetNumberOfElements(prhs[1]), mxGetDoubles(plhs[0]), mxGetDoubles(nh), NULL, NULL, NULL),
+        chk(gsmcal_fcch_scan_batch(ctx(), U8_PTR(prhs[0]), (int)f, (long)(rows2n / 2), REAL_PTR(prhs[1]),
+                                   (int)mxGetNumberOfElements(prhs[1]), REAL_PTR(plhs[0]), REAL_PTR(nh), NULL, NULL, NULL),
             "gsmcal_fcch_scan");
         if (nlhs > 1) plhs[1] = nh;
     }

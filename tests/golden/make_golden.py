@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import gsmcal  # noqa: E402
 from oracle import gsmcal_oracle as o  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refvec  # noqa: E402
 
 synth = gsmcal.synth
 FC = 957.4e6
@@ -43,6 +45,9 @@ def main():
             "carrier_ppm": [f(float(v)) for v in out["carrier_ppm"]],
             "total_sampling_ppm": f(out["total_sampling_ppm"]), "total_carrier_ppm": f(out["total_carrier_ppm"]),
             "r_len": out["r_len"],
+            # SURVEY 8c front-end vectors: DC-removed checksum + first/last 16 values (raw2iq.m:5-8), FIR output at 32 probe
+            # indices (gsm_sync_demod.m:110); 1-based indices, same record as tests/golden/make_reference_vectors.m writes
+            "front_end": refvec.front_end_record(o, raw, coef)[0],
         })
     scans = []
     for arfcn in range(6):
@@ -50,7 +55,8 @@ def main():
         sc = o.scan_capture(raw, coef30)
         scans.append({"dongle": 50, "arfcn": arfcn, "num_frames": 64, "bcch": arfcn % 2 == 0,
                       "raw_sum": int(np.sum(raw.astype(np.uint64))), "coarse_pos": sc["coarse_pos"].tolist(),
-                      "coarse_snr": sc["coarse_snr"].tolist(), "snr": sc["snr"], "num_hit": sc["num_hit"]})
+                      "coarse_snr": sc["coarse_snr"].tolist(), "snr": sc["snr"], "num_hit": sc["num_hit"],
+                      "front_end": refvec.front_end_record(o, raw, coef30)[0]})
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "calib_golden.json"), "w") as fh:
         json.dump({"carrier_freq": FC, "seed": synth.DEFAULT_SEED, "generator": "tests/golden/make_golden.py",
                    "cases": cases, "scans": scans}, fh, indent=1)

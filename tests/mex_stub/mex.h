@@ -3,7 +3,9 @@
  * The build image has no MATLAB, so mex/gsmcal_mex.c can never be built here.  tests/test_abi_cpu.py compiles every
  * gateway target with `gcc -fsyntax-only` against these declarations: a check of syntax and of every call into
  * include/gsmcal.h (argument counts and types), not of MATLAB semantics.  Only the subset of the published MEX C API
- * (interleaved-complex, -R2018a) that the gateway uses is declared. */
+ * that the gateway uses is declared -- the interleaved-complex one (-R2018a) by default, the split-complex one
+ * (mxGetPr / mxGetPi, every release and still the default of `mex`) with -DGSMCAL_STUB_SPLIT.  Each mode declares ONLY its
+ * own accessors, so a gateway path that reaches for the other API's functions does not compile. */
 #ifndef GSMCAL_TEST_MEX_STUB_H
 #define GSMCAL_TEST_MEX_STUB_H
 #include <stddef.h>
@@ -21,9 +23,17 @@ size_t mxGetNumberOfElements(const mxArray*);
 int mxIsComplex(const mxArray*);
 int mxIsUint8(const mxArray*);
 double mxGetScalar(const mxArray*);
+#ifdef GSMCAL_STUB_SPLIT
+#define MX_HAS_INTERLEAVED_COMPLEX 0
+double* mxGetPr(const mxArray*);
+double* mxGetPi(const mxArray*);
+void* mxGetData(const mxArray*);
+#else
+#define MX_HAS_INTERLEAVED_COMPLEX 1
 double* mxGetDoubles(const mxArray*);
 mxComplexDouble* mxGetComplexDoubles(const mxArray*);
 mxUint8* mxGetUint8s(const mxArray*);
+#endif
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray* mxCreateDoubleScalar(double v);
 mxArray* mxCreateLogicalScalar(mxLogical v);

@@ -79,15 +79,84 @@ MEX_TARGETS = ("raw2iq", "chn_filter_8x_4x", "chn_filter_4x", "move_fft_snr_runt
                "total_ppm_calculation", "gsmcal_calibrate", "gsmcal_fcch_scan")
 
 
+@pytest.mark.parametrize("api", ["interleaved", "split"])
 @pytest.mark.parametrize("target", MEX_TARGETS)
-def test_mex_gateway_compiles_against_the_abi(target):
+def test_mex_gateway_compiles_against_the_abi(target, api):
     """mex/gsmcal_mex.c cannot be BUILT here (no MATLAB): every target goes through `gcc -fsyntax-only` against a
-    declaration-only mex.h (tests/mex_stub) -- syntax and every call into include/gsmcal.h are checked."""
+    declaration-only mex.h (tests/mex_stub) -- syntax and every call into include/gsmcal.h are checked, once per MEX
+    complex-storage API (interleaved = -R2018a; split = mxGetPr / mxGetPi, the API of the reference's era: SURVEY 8b)."""
     import subprocess
-    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-std=c99", f"-DGSMCAL_FN_{target}",
-                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "mex_stub"),
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-std=c99", f"-DGSMCAL_FN_{target}"] +
+                       (["-DGSMCAL_STUB_SPLIT"] if api == "split" else []) +
+                       ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "mex_stub"),
                         os.path.join(ROOT, "mex", "gsmcal_mex.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_mex_split_complex_helpers_round_trip(tmp_path):
+    """The split-API helpers of the gateway (interleave on the way in, de-interleave on the way out) run for real: the
+    gateway source is compiled with the split stub plus a few-line mxArray implementation, and a complex column goes
+    in through cplx_in() and back out through cplx_col()."""
+    import subprocess
+    drv = tmp_path / "drv.c"
+    drv.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#define GSMCAL_FN_total_ppm_calculation 1
+#include "gsmcal_mex.c"
+struct mxArray_tag { size_t m, n; int cplx; double *pr, *pi; };
+size_t mxGetM(const mxArray* a) { return a->m; }
+size_t mxGetN(const mxArray* a) { return a->n; }
+size_t mxGetNumberOfElements(const mxArray* a) { return a->m * a->n; }
+int mxIsComplex(const mxArray* a) { return a->cplx; }
+int mxIsUint8(const mxArray* a) { (void)a; return 0; }
+double mxGetScalar(const mxArray* a) { return a->pr[0]; }
+double* mxGetPr(const mxArray* a) { return a->pr; }
+double* mxGetPi(const mxArray* a) { return a->pi; }
+void* mxGetData(const mxArray* a) { return a->pr; }
+mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity f) {
+    mxArray* a = calloc(1, sizeof(*a)); a->m = m; a->n = n; a->cplx = f == mxCOMPLEX;
+    a->pr = calloc(m * n + 1, sizeof(double)); a->pi = a->cplx ? calloc(m * n + 1, sizeof(double)) : NULL; return a; }
+mxArray* mxCreateDoubleScalar(double v) { mxArray* a = mxCreateDoubleMatrix(1, 1, mxREAL); a->pr[0] = v; return a; }
+mxArray* mxCreateLogicalScalar(mxLogical v) { return mxCreateDoubleScalar(v); }
+mxArray* mxCreateCellMatrix(mwSize m, mwSize n) { return mxCreateDoubleMatrix(m, n, mxREAL); }
+void mxSetCell(mxArray* c, mwIndex i, mxArray* v) { (void)c; (void)i; (void)v; }
+void* mxMalloc(size_t n) { return malloc(n); }
+void* mxCalloc(size_t n, size_t s) { return calloc(n, s); }
+void mxFree(void* p) { free(p); }
+int mexAtExit(void (*fn)(void)) { (void)fn; return 0; }
+void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...) { (void)id; (void)fmt; exit(3); }
+int gsmcal_ctx_create(int d, gsmcal_ctx** o) { (void)d; (void)o; return -1; }
+void gsmcal_ctx_destroy(gsmcal_ctx* c) { (void)c; }
+const char* gsmcal_last_error(gsmcal_ctx* c) { (void)c; return ""; }
+int gsmcal_total_ppm_calculation(const double* in, int n, double* out) { (void)in; (void)n; *out = 0; return 0; }
+int main(void) {
+    mwSize n = 0, i;
+    mxArray* a = mxCreateDoubleMatrix(5, 1, mxCOMPLEX);
+    for (i = 0; i < 5; ++i) { a->pr[i] = 1.5 + i; a->pi[i] = -0.25 * i; }
+    const double* inter = cplx_in(a, &n);
+    if (n != 5) return 1;
+    for (i = 0; i < 5; ++i) if (inter[2 * i] != 1.5 + i || inter[2 * i + 1] != -0.25 * i) return 2;
+    mxArray* b = cplx_col(inter, n);
+    if (!b->cplx || b->m != 5 || b->n != 1) return 4;
+    for (i = 0; i < 5; ++i) if (b->pr[i] != a->pr[i] || b->pi[i] != a->pi[i]) return 5;
+    mxArray* r = mxCreateDoubleMatrix(3, 1, mxREAL);          /* a real input is widened with zero imaginary parts */
+    r->pr[0] = 7; r->pr[1] = 8; r->pr[2] = 9;
+    inter = cplx_in(r, &n);
+    if (n != 3 || inter[0] != 7 || inter[1] != 0 || inter[4] != 9 || inter[5] != 0) return 6;
+    (void)ctx; (void)chk; (void)scalar;
+    puts("split helpers ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "drv"
+    r = subprocess.run(["gcc", "-std=c99", "-DGSMCAL_STUB_SPLIT", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tests", "mex_stub"), "-I" + os.path.join(ROOT, "mex"), str(drv), "-o", str(exe), "-lm"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "split helpers ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_mex_gateway_covers_every_reference_function():

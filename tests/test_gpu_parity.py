@@ -7,6 +7,7 @@ estimated tone frequency into k*c*1e-14 ~ 1e-9 rad at k = 1e6, so streams cannot
 import json
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -278,6 +279,30 @@ def test_calibrate_batch_against_golden_vectors(g, setup, gold):
                "total_sampling_ppm": num(c["total_sampling_ppm"]), "total_carrier_ppm": num(c["total_carrier_ppm"])}
         parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
         assert out["r_len"][i] == c["r_len"]
+
+
+def test_front_end_against_golden_probe_vectors(g, setup, gold):
+    """SURVEY 8c front-end vectors from tests/golden/calib_golden.json (the record tests/golden/make_reference_vectors.m
+    writes for the reference itself): raw2iq checksums and first / last 16 values, channel-filter output at 32 probe
+    indices -- HIP raw2iq and the batch front end at full rate (decimation 1) on the sync and the scanner geometry."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import refvec
+
+    class HipFrontEnd:                                     # the two calls refvec.front_end_record makes, on the GPU
+        def __init__(self, raw):
+            self.raw = raw
+
+        def raw2iq(self, a):
+            return g.raw2iq(self.raw)
+
+        def matlab_filter(self, coef, r):
+            return g.frontend_batch(self.raw[None, :], coef, 1)[0]
+
+    for case, coef in [(gold["cases"][0], setup["coef"]), (gold["cases"][3], setup["coef"]), (gold["scans"][0], setup["coef30"])]:
+        raw = g.synth.make_stream(dongle=case["dongle"], arfcn=case["arfcn"], num_frames=case["num_frames"], bcch=case.get("bcch", True))[0]
+        assert int(np.sum(raw.astype(np.uint64))) == case["raw_sum"]
+        fe = refvec.front_end_record(HipFrontEnd(raw), raw, coef)[0]
+        assert refvec.compare(case["front_end"], fe, f"dongle {case['dongle']} arfcn {case['arfcn']}", val_rtol=1e-12) == []
 
 
 def test_calibrate_batch_against_live_oracle_with_stream_output(g, setup):
@@ -682,3 +707,39 @@ def test_outputs_in_pinned_host_memory(g, ctx, setup):
     ctx.check(rc, "gsmcal_fcch_scan_batch_dev")
     ctx.sync()
     assert np.array_equal(out.numpy()[:, 0], sc["snr"]) and np.array_equal(out.numpy()[:, 1], sc["num_hit"])
+
+
+def test_multi_lane_graph_replay_of_a_256_stream_batch(g, ctx, setup):
+    """VERDICT r2 (missing 6): 256 streams = four lanes (four HIP streams forked off the context's); the second identical
+    gsmcal_calibrate_batch_dev call captures the whole fork/join plan into a hipGraph, the third replays it.  Every call
+    must give the oracle's rows (8 distinct streams tiled, unselected: calibrating and rejected ones)."""
+    import ctypes as C
+    import torch
+    dp = g._lib.c_double_p
+    distinct = [g.synth.make_stream(dongle=300 + i, num_frames=102)[0] for i in range(8)]
+    D = 256
+    raw = np.stack([distinct[i % 8] for i in range(D)])
+    N = raw.shape[1] // 2
+    raw_t = torch.from_numpy(raw).cuda()
+    coef, ts, cf = setup["coef"], setup["ts"], np.full(D, FC)
+    table_t = torch.zeros((D, g.TABLE_COLS), dtype=torch.float64, device="cuda")
+    pos_t = torch.zeros((D, 2, g.MAX_POS_ROWS), dtype=torch.float64, device="cuda")
+    orc = [o.calibrate_stream(distinct[i], coef, ts, FC) for i in range(8)]
+    for call in range(3):
+        table_t.fill_(-7.0)
+        pos_t.fill_(-7.0)
+        torch.cuda.synchronize()
+        rc = ctx.lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, coef.ctypes.data_as(dp), len(coef),
+                                                ts.ctypes.data_as(dp), len(ts), cf.ctypes.data_as(dp),
+                                                C.c_void_p(table_t.data_ptr()), C.c_void_p(pos_t.data_ptr()), None, None)
+        ctx.check(rc, "gsmcal_calibrate_batch_dev")
+        ctx.sync()
+        table, pos = table_t.cpu().numpy(), pos_t.cpu().numpy()
+        det = g.last_batch_details(8, ctx=ctx)
+        for i in range(8):
+            k = int(table[i, 7])
+            pi = -np.ones((k, 2)) if table[i, 8] == -1.0 else np.ascontiguousarray(pos[i, :, :k].T)
+            parity.compare_stream(orc[i], table[i], det, i, pi)
+        for i in range(8, D):                                # every copy of a stream, whichever lane it ran on
+            assert np.array_equal(table[i], table[i % 8], equal_nan=True), f"call {call}, stream {i}"
+            assert np.array_equal(pos[i], pos[i % 8]), f"call {call}, stream {i}"

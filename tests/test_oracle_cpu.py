@@ -3,6 +3,7 @@
 import json
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -183,6 +184,15 @@ def test_golden_vectors_reproduce():
                 assert math.isinf(out[k])
             else:
                 assert abs(out[k] - g) <= 1e-9 * max(1.0, abs(g))
+        # SURVEY 8c front-end vectors: DC-removed checksums, first / last 16 values, FIR output at 32 probe indices
+        sys.path.insert(0, GOLD)
+        import refvec
+        fe = refvec.front_end_record(o, raw, coef)[0]
+        assert refvec.compare(case["front_end"], fe, f"dongle {case['dongle']}", val_rtol=1e-12) == []
+    coef30 = o.fir1(30, 200e3 / synth.FS)
+    sc = gold["scans"][0]
+    raw, _ = synth.make_stream(dongle=sc["dongle"], arfcn=sc["arfcn"], num_frames=sc["num_frames"], bcch=sc["bcch"])
+    assert refvec.compare(sc["front_end"], refvec.front_end_record(o, raw, coef30)[0], "scan 0", val_rtol=1e-12) == []
 
 
 # ---- second, literal restatement (oracle/gsmcal_oracle_literal.py) against the vectorised oracle ------------------------
