@@ -51,11 +51,12 @@ struct ProfRec {
 #define MAX_LANES 16
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr;
+    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr, xch;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
+    int xch_S = 0, xch_H = 0;          // geometry the exchange block / launch counters of k_post_chain_r were cleared for
     int win_l0_len = 0, win_l0_H = 0;  // > 0: `win` holds the fine search's level-0 windows (this length each, H per stream) of the call in progress
 };
 
@@ -97,6 +98,8 @@ struct gsmcal_ctx {
     double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
     bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
+    bool post_repl = true;          // GSMCAL_POST_REPL=0: k_post_chain (last arriver decides, state through memory) instead of k_post_chain_r
+    bool lane_stagger = false;      // GSMCAL_LANE_STAGGER=1: calibration lanes start one front kernel apart instead of together
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
@@ -267,8 +270,8 @@ GatherArgs gather_args(const Source& src, int level, int len) {
 }
 
 // LDS of a fused gather + estimator kernel: the gather carve followed by `scratch` bytes
-size_t fused_lds(const Source& src, int level, int len, size_t scratch) {
-    return (gather_carve(len, level, src.kind, src.ntaps, true).total + scratch + 15) & ~(size_t)15;
+size_t fused_lds(const Source& src, int level, int len, size_t scratch, bool compact_xs = false) {
+    return (gather_carve(len, level, src.kind, src.ntaps, true, compact_xs).total + scratch + 15) & ~(size_t)15;
 }
 
 int launch_gather(gsmcal_ctx* c, int S, const Source& src, int level, int len, bool tiles, int nwin_grid,
@@ -411,21 +414,35 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             // ---- the fused tail of the chain: verify -> bursts -> SCH windows -> post-SCH bursts in one launch ----
             const int wl_sch = g.sch_nshift - 1 + len_ts;
             const size_t sch_scratch = (size_t)(len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
+            // replicated decisions (k_post_chain_r): the state copy stays in LDS in front of the stages' work area, and
+            // the burst stages stage their (rare) raw-byte fallback without bank padding so that three workgroups still fit a CU
+            const bool repl = c->post_repl && H <= 32;
             size_t lds = vlds;
-            lds = std::max(lds, fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)));
+            lds = std::max(lds, fused_lds(src, lvl + 1, g.nfft, burst_scratch(g), repl));
             lds = std::max(lds, fused_lds(src, lvl + 2, wl_sch, sch_scratch));
-            lds = std::max(lds, fused_lds(src, lvl + 3, g.nfft, burst_scratch(g)));
+            lds = std::max(lds, fused_lds(src, lvl + 3, g.nfft, burst_scratch(g), repl));
             lds = std::max(lds, (sizeof(StreamState) + 15) & ~(size_t)15);
+            if (repl) lds += PCR_STATE_BYTES;
             // only while every workgroup of the launch is resident at once (three 512-thread workgroups per CU): a workgroup
             // waiting at a stream barrier holds its slot, which costs nothing in the latency regime (64 streams: 0.234 vs
             // 0.237 ms per step) and a fifth of the throughput beyond it (256 streams: 0.73 vs 0.63 ms; 1024: 2.53 vs 2.13)
-            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && lds <= 53 * 1024 &&
+            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && lds <= 52 * 1024 &&
                            (long)H * S <= 3L * c->n_cu;
             if (chain->fused) {
                 const size_t need = (size_t)2 * S * sizeof(unsigned);
                 if (c->cur->postctr.cap < need) {
                     RET_IF(ensure(c, c->cur->postctr, need));
                     HIPCHK(c, hipMemsetAsync(c->cur->postctr.p, 0, c->cur->postctr.cap, c->cur->stream));
+                }
+                const size_t need_x = (size_t)S * 2 * 4 * 2 * H * sizeof(unsigned long long);
+                if (repl && (c->cur->xch.cap < need_x || c->cur->xch_S != S || c->cur->xch_H != H)) {
+                    // a new geometry: every granule EMPTY (all ones), launch counters zero.  (Between launches of one geometry the
+                    // kernel keeps the next launch's half of the block EMPTY itself.)
+                    if (c->capturing) return GSMCAL_E_HIP;      // (cannot happen: a captured call repeats the previous call's geometry)
+                    RET_IF(ensure(c, c->cur->xch, need_x));
+                    HIPCHK(c, hipMemsetAsync(c->cur->xch.p, 0xFF, c->cur->xch.cap, c->cur->stream));
+                    HIPCHK(c, hipMemsetAsync(c->cur->postctr.p, 0, c->cur->postctr.cap, c->cur->stream));
+                    c->cur->xch_S = S; c->cur->xch_H = H;
                 }
                 PostChainArgs pa;
                 memset(&pa, 0, sizeof(pa));
@@ -435,6 +452,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 if (c->cur->win_l0_len > 0) {
                     for (GatherArgs* ga : {&pa.ga1, &pa.ga0}) { ga->l0 = win; ga->l0_stream_stride = sstride; ga->l0_win_stride = wstride; ga->l0_len = c->cur->win_l0_len; }
                 }
+                if (repl) { pa.ga1.pad = 1; pa.ga0.pad = 1; }
                 pa.sa = sa_fine;
                 pa.sa.table = chain->table; pa.sa.pos_info_out = chain->pos_info_out; pa.sa.r_len_out = chain->r_len_out;
                 pa.ctr = (unsigned*)c->cur->postctr.p; pa.gen = pa.ctr + S;
@@ -444,7 +462,8 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.win = win; pa.win_stream_stride = sstride; pa.win_stride = wstride;
                 pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
                 pa.with_totals = chain->table ? 1 : 0;
-                LAUNCH(c, k_post_chain, dim3(H, S), dim3(PC_THREADS), lds, st, pa);
+                if (repl) LAUNCH(c, k_post_chain_r, dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
+                else LAUNCH(c, k_post_chain, dim3(H, S), dim3(PC_THREADS), lds, st, pa);
                 CHECK_LAUNCH(c);
                 return 0;
             }
@@ -919,6 +938,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_post_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_post_chain_r, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_equalise, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_fd_training, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -946,6 +966,10 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (sse) c->snr_screen_db = atof(sse);
     const char* fge = getenv("GSMCAL_FUSE_GATHER");
     if (fge) c->fuse_fine_gather = atoi(fge) != 0;
+    const char* pre_ = getenv("GSMCAL_POST_REPL");
+    if (pre_) c->post_repl = atoi(pre_) != 0;
+    const char* lse = getenv("GSMCAL_LANE_STAGGER");
+    if (lse) c->lane_stagger = atoi(lse) != 0;
     const char* fpe = getenv("GSMCAL_FUSE_POST");
     if (fpe) c->fuse_post = atoi(fpe) != 0;
     const char* pe = getenv("GSMCAL_PRESCREEN");
@@ -984,7 +1008,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.postctr};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.postctr, &L.xch};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1560,7 +1584,12 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const int lo = L.lo, S = L.n;
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
+        if (nl > 1 && c->lane_stagger) {                    // staggered lanes: this lane's front kernel starts when the previous lane's has finished
+            if (!L.front_done) HIPCHK(c, hipEventCreateWithFlags(&L.front_done, hipEventDisableTiming));
+            if (i > 0) HIPCHK(c, hipStreamWaitEvent(L.stream, c->lanes[i - 1].front_done, 0));
+        }
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
+        if (nl > 1 && c->lane_stagger) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
         RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));         // :117 (+ state init, fine setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;

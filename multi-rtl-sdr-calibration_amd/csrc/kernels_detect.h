@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
                                                  const cplx* __restrict__ tw_g, const ChunkRec* __restrict__ rec,
                                                  PeakOut* __restrict__ out, int H,
                                                  const FineCert* __restrict__ cert, int* __restrict__ n_open,
-                                                 unsigned char* smem) {
+                                                 unsigned char* smem, PeakOut* res = nullptr) {   // res: the window's peak instead of out[]
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_open = 0;   // k_fine_chunk is done with the list: clear it for the next batch
     const int wlen = nshift - 1 + nfft;
     cplx* xs = (cplx*)smem;                               // window
@@ -1426,7 +1426,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     if (cert) {
         fc = cert[(size_t)s * H + w];
         if (fc.nch == 0) {                                // fully certified window: the certificate IS the answer
-            if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; peak_store(&out[(size_t)s * H + w], o2); }
+            if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; if (res) *res = o2; else peak_store(&out[(size_t)s * H + w], o2); }
             return;
         }
     }
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     const bool slow = n_over > 0 || n_items > FV_MAX_ITEMS;   // block-uniform; pathological inputs only (e.g. all zeros)
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 3);
     if (n_items == 0 && !slow && fc.p > 0.0) {            // (block-uniform) nothing reaches the bar: the certificate's answer stands
-        if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; peak_store(&out[(size_t)s * H + w], o2); }
+        if (tid == 0) { PeakOut o2; o2.p = fc.p; o2.tie = fc.t; o2.k = fc.k; if (res) *res = o2; else peak_store(&out[(size_t)s * H + w], o2); }
         return;
     }
     const cplx* x = win + (size_t)s * win_stream_stride + (size_t)w * win_stride;
@@ -1535,7 +1535,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
                 best = red_p[i]; bt = red_t[i]; bk = red_k[i];
             }
         PeakOut o2; o2.p = best; o2.tie = bt; o2.k = bk;
-        peak_store(&out[(size_t)s * H + w], o2);
+        if (res) *res = o2; else peak_store(&out[(size_t)s * H + w], o2);
     }
 }
 

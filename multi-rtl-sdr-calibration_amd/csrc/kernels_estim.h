@@ -66,7 +66,7 @@ __device__ __forceinline__ PeakOut merge_peaks_coherent(const PeakOut* p, int NB
 template <int GATE>
 __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, const GatherArgs& a, int nfft,
                                                 const cplx* __restrict__ tw_g, int ov, int prior_mode,
-                                                unsigned char* smem) {
+                                                unsigned char* smem, double* res = nullptr) {   // res: {fo, snr} instead of the stores into the state
     __shared__ double red_p[BT_THREADS / 64];
     __shared__ int red_t[BT_THREADS / 64];
     __shared__ double red[2 * (BT_THREADS / 64)];
@@ -81,7 +81,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     StreamState* st = sts + s;
     const int N2 = nfft / 37, ldb = N2 + 1;
     // the window sits in one of the two gather buffers; the other one holds B, the tables go behind the carve
-    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true);
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true, a.pad != 0);
     cplx* B = (xs == (cplx*)smem) ? (cplx*)(smem + gc.off_region1) : (cplx*)smem;
     cplx* w37 = (cplx*)(smem + gc.total);
     cplx* wN2 = w37 + 40;
@@ -210,7 +210,8 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         const double cnt = (double)(nfft - 1);
         const double phase = atan2(ti / cnt, tr / cnt);
         sh_phase = phase;
-        coherent_store(&st->fo_burst[w], sampling_rate * (ipr + phase) / TWO_PI_D);   // :155
+        const double fo = sampling_rate * (ipr + phase) / TWO_PI_D;                    // :155
+        if (res) res[0] = fo; else coherent_store(&st->fo_burst[w], fo);
     }
     BT_STAMP(3);
     if (!GATE) return;
@@ -254,7 +255,8 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
             double sig = 0.0;
             for (int k = 0; k < 3; ++k) sig += P[k];
             for (int k = nb - 2; k < nb; ++k) sig += P[k];
-            coherent_store(&st->snr_burst[w], 10.0 * log10(sig / noi));
+            const double sn = 10.0 * log10(sig / noi);
+            if (res) res[1] = sn; else coherent_store(&st->snr_burst[w], sn);
         }
     }
     BT_STAMP(4);
@@ -269,13 +271,13 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
 #define SCH_PARTS 4
 __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, const GatherArgs& a,
                                                 const cplx* __restrict__ ts, int len_ts, int nshift,
-                                                unsigned char* smem) {
+                                                unsigned char* smem, double* res = nullptr) {   // res: {SCH_pos, edge flag}
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 0);
     cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
     if (!xs) return;
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 1);
-    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true);
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true, a.pad != 0);
     cplx* tc = (cplx*)(smem + gc.total);                                  // conj(ts), behind the gather carve
     cplx* part = tc + len_ts;                                             // nshift * SCH_PARTS partial sums
     double* cv = (double*)(part + nshift * SCH_PARTS);                    // nshift correlation powers
@@ -337,8 +339,13 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
             if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
         }
         if (tid == 0) {
-            coherent_store(&st->sch_first[w], (double)(st_i64(&st->win_start[w]) + 1 + mi));   // sp + max_idx - 1
-            if (mi == 0 || mi == nshift - 1) atomicOr(&st->sch_edge, 1);    // :59
+            const double sp = (double)(st_i64(&st->win_start[w]) + 1 + mi);   // sp + max_idx - 1
+            const bool edge = mi == 0 || mi == nshift - 1;                    // :59
+            if (res) { res[0] = sp; res[1] = edge ? 1.0 : 0.0; }
+            else {
+                coherent_store(&st->sch_first[w], sp);
+                if (edge) atomicOr(&st->sch_edge, 1);
+            }
         }
     }
 }
@@ -917,5 +924,138 @@ k_post_chain(StreamState* __restrict__ sts, PostChainArgs a) {
         __syncthreads();
         if (sh_fin) step_body<true>(sts, a.sa, a.with_totals ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, a.lvl_post, 0,
                                     blockIdx.y, (StreamState*)smem);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_post_chain_r: k_post_chain with REPLICATED decision steps.  Every workgroup of a stream keeps its own copy of the
+// stream's state in LDS for the whole launch.  A stage ends with each workgroup publishing its two result words (tone
+// frequency + gate SNR, SCH position + edge flag, peak power + shift/bin) as 8-byte write-through granules in the stream's
+// exchange block; it then reads the granules of all H workgroups of its stream (one lane per granule, polling past the
+// L1 until none is EMPTY) and runs the reference's decision step ITSELF on its own LDS copy -- the same instructions on
+// the same inputs in every workgroup, so all copies stay identical.  No counter, no last arriver, no state written and read
+// back through memory, no flag: after the slowest workgroup of the stream has published, its peers continue as soon as
+// they see its granule (~1 us) and have run the step on LDS (~1.5 us).  Workgroup 0 of the stream writes the table row and
+// the final state.  The exchange block is double-buffered by the parity of a per-stream launch counter (each workgroup
+// clears its own granules of the other parity on entry), so the launch can be replayed from a hipGraph unchanged.
+// EMPTY = all ones (a NaN no computation produces: published NaNs are canonicalised).
+// ------------------------------------------------------------------------------------------------
+#define PCR_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define PCR_STATE_BYTES ((sizeof(StreamState) + 15) & ~(size_t)15)
+
+__device__ __forceinline__ unsigned long long pcr_word(double v) {
+    return v != v ? 0x7FF8000000000000ull : (unsigned long long)__double_as_longlong(v);
+}
+
+// publish r0, r1 as this workgroup's granules of `stage`, then collect the stream's 2*H granules into all[] (LDS)
+__device__ __forceinline__ void pcr_exchange(unsigned long long* __restrict__ slots, int H, int w, unsigned long long r0,
+                                             unsigned long long r1, unsigned long long* all, int* sh_status, bool collect) {
+    const int tid = threadIdx.x;
+    if (tid < 2) __hip_atomic_store(slots + 2 * w + tid, tid ? r1 : r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!collect) return;
+    if (tid < 64) {
+        const bool mine = tid < 2 * H;
+        unsigned long long v = PCR_EMPTY;
+        long spins = 0;
+        bool bad = false;
+        while (true) {
+            if (mine && v == PCR_EMPTY) v = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__ballot(mine && v == PCR_EMPTY)) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 40000000L) { bad = true; break; }      // a peer never came (not observed): fail, do not hang the queue
+        }
+        if (mine) all[tid] = v;
+        if (bad && tid == 0 && *sh_status >= 0) *sh_status = GSMCAL_E_HIP;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long long* __restrict__ xch, unsigned* __restrict__ epoch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    __shared__ unsigned long long all[64];
+    __shared__ double res[2];
+    __shared__ PeakOut pk;
+    const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x, H = gridDim.x, lane = tid;
+    StreamState* sh = (StreamState*)smem_all;                       // this workgroup's copy of the stream's state
+    unsigned char* smem = smem_all + PCR_STATE_BYTES;               // the stages' work area
+    StreamState* shv = sh - s;                                      // so that the stage bodies' `sts + blockIdx.y` is the LDS copy
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    const unsigned par = epoch[s] & 1u;
+    unsigned long long* mine_x = xch + ((size_t)s * 2 + par) * 4 * 2 * H;        // [stage][w][2]
+    unsigned long long* other_x = xch + ((size_t)s * 2 + (par ^ 1u)) * 4 * 2 * H;
+    if (tid < 8) __hip_atomic_store(other_x + (size_t)(tid >> 1) * 2 * H + 2 * w + (tid & 1), PCR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const uint4* src = (const uint4*)(sts + s);
+        uint4* dst = (uint4*)sh;
+        for (int i = tid; i < (int)(sizeof(StreamState) / 16); i += PC_THREADS) dst[i] = src[i];
+    }
+    if (tid == 0) { pk.p = -1.0; pk.tie = 0; pk.k = 0; res[0] = 0.0; res[1] = 0.0; }
+    __syncthreads();
+    // ---- stage 0: the fine search's exact last word per window -> FINE_DECIDE (FCCH_fine_correction.m:52-137) ----
+    fine_verify_body<PC_THREADS>(shv, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
+                                 a.cert, a.n_open, smem, &pk);
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1);
+    pcr_exchange(mine_x, H, w, pcr_word(pk.p), (unsigned long long)(unsigned)pk.tie | ((unsigned long long)(unsigned)pk.k << 32), all,
+                 &sh->status, true);
+    if (tid < 64) {
+        if (lane < sh->n_win && lane < MAXH && lane < H) {
+            sh->fine_first[lane] = (double)(sh->win_start[lane] + 1 + (int)(all[2 * lane + 1] & 0xffffffffu));   // sp + max_idx - 1
+            sh->prior_bin[lane] = (int)(all[2 * lane + 1] >> 32);
+        }
+        wsync();
+        d_fine_decide(sh, a.sa.ov, a.lvl_fine, a.sa.P, lane); wsync();
+        if (lane == 0) { res[0] = 0.0; res[1] = 0.0; }
+    }
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 3);
+    // ---- stage 1: bursts of the resampled stream (:141-165, :185-196) -> CARRIER_DECIDE + SCH window setup ----
+    burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res);
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 4);
+    pcr_exchange(mine_x + 2 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    if (tid < 64) {
+        if (lane < H && lane < MAXH) {
+            sh->fo_burst[lane] = __longlong_as_double((long long)all[2 * lane]);
+            sh->snr_burst[lane] = __longlong_as_double((long long)all[2 * lane + 1]);
+        }
+        wsync();
+        d_carrier_decide(sh, s, a.sa.ov, a.sa.carrier_freq, a.lvl_fine, a.sa.P, lane); wsync();
+        d_sch_setup(sh, a.sa.ov, a.sa.len_ts, a.lvl_sch, a.sa.P, lane); wsync();
+        if (lane == 0) { res[0] = 0.0; res[1] = 0.0; }
+    }
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 6);
+    // ---- stage 2: SCH_corr_rate_correction.m:45-55 -> SCH_DECIDE (:59-181) + post-SCH window setup ----
+    const int n_sch_win = sh->n_win;
+    window_sch_body(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 7);
+    pcr_exchange(mine_x + 4 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    if (tid < 64) {
+        const bool act = lane < H && lane < MAXH && lane < n_sch_win;
+        if (act) sh->sch_first[lane] = __longlong_as_double((long long)all[2 * lane]);
+        const unsigned long long edge = __ballot(act && __longlong_as_double((long long)all[2 * lane + 1]) != 0.0);
+        if (lane == 0 && edge) sh->sch_edge = 1;
+        wsync();
+        d_sch_decide(sh, a.sa.ov, a.lvl_sch, a.sa.P, lane); wsync();
+        d_post_setup(sh, a.sa.ov, a.lvl_post, a.sa.P, lane); wsync();
+        if (lane == 0) { res[0] = 0.0; res[1] = 0.0; }
+    }
+    __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 9);
+    // ---- stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124) ----
+    burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res);
+    __syncthreads();
+    pcr_exchange(mine_x + 6 * H, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
+    if (w != 0) return;                                             // workgroup 0 finishes the stream
+    if (tid < 64) {
+        if (lane < H && lane < MAXH) sh->fo_burst[lane] = __longlong_as_double((long long)all[2 * lane]);
+        wsync();
+        d_post_decide(sh, s, a.sa.ov, a.sa.carrier_freq, a.lvl_post, lane); wsync();
+        if (a.with_totals) d_totals(sh, s, a.sa.table, a.sa.pos_info_out, a.sa.r_len_out, lane);
+        StateLds::store(sts + s, sh, lane);
+        if (lane == 0) epoch[s] = par + 1u;                         // (only the parity matters)
     }
 }

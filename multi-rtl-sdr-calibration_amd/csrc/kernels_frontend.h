@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) k_fir_arr(const cplx* __restrict__ in, lo
 // LDS: two ping-pong buffers of (len+8) complex doubles + the raw bytes for SRC_RAW.
 // ------------------------------------------------------------------------------------------------
 struct GatherArgs {
-    int src_kind, level, len, tiles, ntaps, pad;
+    int src_kind, level, len, tiles, ntaps, pad;   // pad != 0: compact_xs (see gather_carve)
     const uint8_t* raw; long raw_stride;     // bytes per stream
     const cplx* arr;    long arr_stride;     // elements per stream
     const double* coef;
@@ -606,15 +606,21 @@ __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 // 4): y[i] = sum_k coef[k] x[i-k], every accumulator taking its taps oldest first (transposed direct-form order) -- the
 // one FIR loop of gather_core and of k_fine_cert's fused window build, so both give bit-identical level-0 samples.
 // NTP > 0: the tap count is a compile-time constant (the production fir1(46) filter): two trips per iteration with known
-// bounds, so the LDS reads of a trip are issued under the FMAs of the one before.  (Unrolled completely the compiler hoists
-// every coefficient and sample load: 256 registers and scratch.)
+// bounds.  (Unrolled completely the compiler hoists every coefficient and sample load: 256 registers and scratch.)
+// Tried and dropped (round 3): the taps through scalar loads from constant-address-space memory instead of LDS -- a third
+// of this loop's LDS bytes are coefficient broadcasts, and the 1024-stream step gained 2.5 % -- but SMEM shares the LDS
+// counter (lgkmcnt), every wait for a tap became a wait for the sample reads in flight, and the 64-stream step lost 3 us;
+// pipelining it by hand (next trip's samples and taps requested before this trip's FMAs) cost registers the 80-register
+// burst kernels do not have (scratch in the loop).
+// PAD = false: the input is staged without xs_pad's bank padding (gather_carve's compact_xs).
 // ------------------------------------------------------------------------------------------------
-template <int NTP>
+template <int NTP, bool PAD = true>
 __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const double* __restrict__ c_s, int i0, int ntp_rt,
                                          cplx* y0, cplx* y1, cplx* y2, cplx* y3) {
+#define XSP(p_) (PAD ? xs_pad(p_) : (p_))
     const int ntp = NTP > 0 ? NTP : ntp_rt;
     double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
-    cplx w0 = xq[xs_pad(i0)], w1 = xq[xs_pad(i0 + 1)], w2 = xq[xs_pad(i0 + 2)], w3 = xq[xs_pad(i0 + 3)];
+    cplx w0 = xq[XSP(i0)], w1 = xq[XSP(i0 + 1)], w2 = xq[XSP(i0 + 2)], w3 = xq[XSP(i0 + 3)];
 #define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
     ar0 = fma(C, A.x, ar0); ai0 = fma(C, A.y, ai0);                     \
     ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);                     \
@@ -626,7 +632,7 @@ __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const doub
     int t = 0;
 #pragma unroll 2
     for (; t + 4 <= ntp; t += 4) {
-        const cplx* nx = xq + xs_pad(i0 + t + 4);
+        const cplx* nx = xq + XSP(i0 + t + 4);
         const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
         const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
         GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
@@ -641,9 +647,10 @@ __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const doub
         GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
         w0 = w1; w1 = w2; w2 = w3;
         ++p;
-        w3 = xq[xs_pad(p)];
+        w3 = xq[XSP(p)];
     }
 #undef GSMCAL_FIR_TAP
+#undef XSP
     *y0 = make_double2(ar0, ai0); *y1 = make_double2(ar1, ai1); *y2 = make_double2(ar2, ai2); *y3 = make_double2(ar3, ai3);
 }
 
@@ -654,11 +661,13 @@ struct GatherCarve {
     size_t off_coef, off_raw, off_rot, total;
 };
 #define GC_ROT_A 72                     /* rotator table: S | A[0..GC_ROT_A) | B[0..32): windows of up to 32*GC_ROT_A samples */
-__host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind, int ntaps, bool to_lds) {
+// compact_xs: the complex input of the raw-source FIR is staged without bank-conflict padding (5 KB less for a burst window;
+// k_post_chain's burst stages, where that path is the rare fallback for a burst outside every fine window)
+__host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind, int ntaps, bool to_lds, bool compact_xs = false) {
     GatherCarve g;
     g.bufn = (level >= 1 || to_lds) ? (size_t)len + 40 : 0;          // +40: room for B[37][N2+1] of the fused kernels
     const size_t span_max = (size_t)len + 8 + ntaps + 24;
-    const size_t xs_n = kind == SRC_RAW ? span_max + span_max / 4 + 16 : 0;   // padded input (raw sources only)
+    const size_t xs_n = kind == SRC_RAW ? (compact_xs ? span_max + 16 : span_max + span_max / 4 + 16) : 0;   // (padded) input, raw sources only
     const bool need_buf1 = level >= 2 || (to_lds && level >= 1) || to_lds;
     size_t r1 = need_buf1 ? g.bufn : 0;
     if (xs_n > r1) r1 = xs_n;
@@ -686,7 +695,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     // LDS carve (GatherCarve, shared with the host and the fused kernels):
     //   buf0 | region1 = buf1 ALIASED WITH xs (padded complex input) | coef | raw ushorts
     // xs is dead once level 0 is in buf0, and buf1 is first written at level 1, so they share storage.
-    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, to_lds);
+    const bool compact = a.pad != 0;
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, to_lds, compact);
     cplx* buf0 = (cplx*)smem;
     cplx* buf1 = (cplx*)(smem + gc.off_region1);
     cplx* xs = buf1;
@@ -813,7 +823,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
                 const unsigned short q = r_s[off + i];
                 v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
             }
-            xs[xs_pad(i)] = v;
+            xs[compact ? i : xs_pad(i)] = v;
         }
         __syncthreads();
         GC_STAMP(11);
@@ -821,7 +831,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
             cplx y0, y1, y2, y3;
-            if (ntp == 47) fir4_lds<47>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            if (compact) fir4_lds<0, false>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            else if (ntp == 47) fir4_lds<47>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             else fir4_lds<0>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             out0[i0] = y0;
             if (i0 + 1 < cnt0) out0[i0 + 1] = y1;
