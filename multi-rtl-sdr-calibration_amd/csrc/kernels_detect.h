@@ -1673,14 +1673,26 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             {   // raw2iq.m:6-8 from the registers: staged sample i = 8*tid + u - (first - first_al); entries span .. span+7 are 0
                 const int i_base = 8 * tid - (int)(first - first_al);
                 const unsigned wv[4] = {pre.x, pre.y, pre.z, pre.w};
+                const long g_base = first + i_base;
+                if (i_base >= 0 && i_base + 8 <= span && g_base >= 0 && g_base + 8 <= n0) {
+                    // the usual chunk: all eight samples inside the span and the stream -- no per-sample tests, and two
+                    // 16-byte-aligned groups of four padded slots (i_base is a multiple of 8 here only when first is aligned, so
+                    // the stores stay per sample; the tests were most of this loop)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i_base + u;
-                    const long g = first + i;
-                    const unsigned q = (wv[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
-                    cplx v = make_double2(0.0, 0.0);
-                    if (i < span && g >= 0 && g < n0) v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
-                    if (i >= 0 && i < span + 8) xq[xs_pad(i)] = v;
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned q = wv[u >> 1] >> (16 * (u & 1));
+                        xq[xs_pad(i_base + u)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i_base + u;
+                        const long g = first + i;
+                        const unsigned q = (wv[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+                        cplx v = make_double2(0.0, 0.0);
+                        if (i < span && g >= 0 && g < n0) v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
+                        if (i >= 0 && i < span + 8) xq[xs_pad(i)] = v;
+                    }
                 }
             }
             __syncthreads();
@@ -1799,15 +1811,20 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     // that the groups of a wave read different LDS banks (the 8 lanes of a group share the sample: broadcast).
     for (int m = c; m < nM; m += nthr / FC_NB) {
         const int xb0 = B * m;
-        const cplx* tb = tw1 + j * ld1;
+        // B divides 128, so the block's B samples sit contiguously behind FC_XP(xb0); sample and twiddle share one running byte
+        // offset that wraps inside the block (two integer instructions per step instead of the index -> padded index -> address
+        // chain for each of the two reads)
+        const unsigned char* xp = (const unsigned char*)(xs + FC_XP(xb0));
+        const unsigned char* tp = (const unsigned char*)(tw1 + j * ld1);
+        const unsigned wrap = (unsigned)B * (unsigned)sizeof(cplx) - 1u;
+        unsigned o = (unsigned)(c & (B - 1)) * (unsigned)sizeof(cplx);
         double ar = 0.0, ai = 0.0;
-        int b = c & (B - 1);
 #pragma unroll 4
         for (int i = 0; i < B; ++i) {
-            const cplx v = xs[FC_XP(xb0 + b)], t = tb[b];
+            const cplx v = *(const cplx*)(xp + o), t = *(const cplx*)(tp + o);
             ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
             ai = fma(v.x, t.y, fma(v.y, t.x, ai));
-            b = (b + 1) & (B - 1);
+            o = (o + (unsigned)sizeof(cplx)) & wrap;
         }
         Sp[j * nM + m] = make_double2(ar, ai);
     }
@@ -1835,12 +1852,14 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         if (lane == 0) red_p[wave] = e0;
         const int per = (nstep + nthr - 1) / nthr;
         const int i0 = tid * per < nstep ? tid * per : nstep, i1 = i0 + per < nstep ? i0 + per : nstep;
+        // |d_q| in fp32 (v_sqrt_f32 is one instruction, the fp64 square root a dozen): C(t) only has to be an UPPER bound of
+        // the slack, each term is scaled up by 1 + 2^-20 > the rounding of the fp32 conversion and square root (< 2^-22)
         double loc = 0.0, locd = 0.0;
         for (int q = i0; q < i1; ++q) {
             const cplx a1 = xs[FC_XP(q + nfft)], b1 = xs[FC_XP(q)];
             loc += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
             const double dr = a1.x - b1.x, di = a1.y - b1.y;
-            locd += sqrt(dr * dr + di * di);
+            locd += (double)(__fsqrt_rn((float)(dr * dr + di * di)) * 1.00000095367431640625f);
         }
         double inc = loc, incd = locd;                    // inclusive scans across the wave
         for (int off = 1; off < 64; off <<= 1) {
@@ -1858,7 +1877,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             const cplx a1 = xs[FC_XP(q + nfft)], b1 = xs[FC_XP(q)];
             run += (a1.x * a1.x + a1.y * a1.y) - (b1.x * b1.x + b1.y * b1.y);
             const double dr = a1.x - b1.x, di = a1.y - b1.y;
-            rund += sqrt(dr * dr + di * di);
+            rund += (double)(__fsqrt_rn((float)(dr * dr + di * di)) * 1.00000095367431640625f);
         }
         if (i1 == nstep && i0 < nstep) { Et[nstep] = run; Cs[FC_XP(nstep)] = (float)rund; }
     }
@@ -1931,9 +1950,11 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             const double NE = (double)nfft * Et[t];
             const float ss = sumS[FC_XP(t)];
             const double R = NE - (double)ss + 4e-6 * NE;
-            double sv = ss <= 3.0e38f ? sqrt(R > 0.0 ? R : 0.0) * (1.0 + 1e-6) : INF;   // (an overflowed fp32 sum bounds nothing)
-            if (!(sv >= 0.0)) sv = INF;                   // NaN input
-            const float sf = (float)sv;
+            // (fp32 square root: s(t) is stored in fp32 anyway; the 1e-6 margin covers both roundings, < 2^-22 together)
+            float sf = ss <= 3.0e38f ? __fsqrt_rn((float)(R > 0.0 ? R : 0.0)) * 1.000001f : __int_as_float(0x7f800000);   // (an overflowed fp32 sum bounds nothing)
+            if (!(sf >= 0.0f)) sf = __int_as_float(0x7f800000);                  // NaN input
+            const double sv = (double)sf;
+            (void)sv;
             sumS[FC_XP(t)] = sf;                          // own range only: s(t) replaces the group sum
             const double cv = (double)Cs[FC_XP(t)];
             mf = fmin(mf, (double)sf - cv);
