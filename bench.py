@@ -33,7 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # HBM bytes per launch from committed rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # HBM bytes per launch from committed rocprofv3 --pmc passes
 
 
 def parse():
@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed HIP-event passes (roofline kernel figure, breakdown)")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-results (config 2, stream mode, scanner path)")
+    ap.add_argument("--cache-streams", default=None,
+                    help="keep the generated synthetic streams in this .npy file and reuse them (profiling passes that rerun the "
+                         "same command; generation is deterministic, the file only saves the host time)")
     return ap.parse_args()
 
 
@@ -221,7 +224,13 @@ def main():
         jobs = list(cand_jobs)
         n_mixed = 64 if (world == 1 and not args.no_sub and args.mode == "table") else 0
         jobs += [(5000 + i, frames, kw) for i, kw in enumerate(mixed_kwargs(n_mixed, 5000))]
-        raws = gen_streams(jobs)
+        cache = args.cache_streams and f"{args.cache_streams}.r{rank}.n{len(jobs)}.f{frames}.npy"
+        if cache and os.path.exists(cache):
+            raws = list(np.load(cache))
+        else:
+            raws = gen_streams(jobs)
+            if cache:
+                np.save(cache, np.stack(raws))
         cand_raw = raws[:ncand]
         mixed_raw = np.stack(raws[ncand:]) if n_mixed else None
 
@@ -478,7 +487,7 @@ def pmc_traffic(kernel, D, N):
         return None, "committed PMC pass is for another batch shape"
     for k, v in pmc.get("hbm_bytes_per_launch", {}).items():
         if k.startswith(kernel[:12]):
-            return v, "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+            return v, "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
     return None, "kernel not in the committed PMC pass"
 
 

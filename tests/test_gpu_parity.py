@@ -447,12 +447,13 @@ def test_front_end_variants_agree(g, setup, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"GSMCAL_CERT": "0"}, {"GSMCAL_PRESCREEN": "0"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2"},
                                  {"GSMCAL_FUSE_GATHER": "0"}, {"GSMCAL_SNR_FULL": "0"}, {"GSMCAL_SNR_SCREEN_DB": "-300"},
-                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}])
+                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}, {"GSMCAL_POST_REPL": "0"}])
 def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     """No certificate (every chunk swept), plain all-bin fp64 search, four concurrent lanes, fine windows through k_gather,
     hop walk on its own spectra / on an unscreened SNR table / falling back because the screening level is above every
     threshold, per-burst gathers filtering their raw bytes again instead of reading the fine windows, the four launches behind
-    the chunk sweep instead of the fused k_post_chain (per-stream barriers inside one launch): identical tables."""
+    the chunk sweep instead of the fused k_post_chain_r (per-stream exchange inside one launch, decision steps replicated in
+    every workgroup), and the fused chain with one deciding workgroup per stream (k_post_chain): identical tables."""
     raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in range(40, 48)])
     ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
     for k, v in env.items():
