@@ -114,6 +114,30 @@ def lib_path():
     return _build.LIB
 
 
+def _share_hip_runtime():
+    """Two HIP runtimes cannot coexist in one process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so; libgsmcal.so
+    names libamdhip64.so.7 and, loaded first, would pull in the system one (/opt/rocm) -- and a later `import torch` would
+    then find "No HIP GPUs".  Loaded after torch it simply resolves to torch's copy (what bench.py and most tests do).  To
+    make the order irrelevant, the wheel's runtime -- when such a wheel is installed and nothing has loaded a HIP runtime
+    yet -- is mapped first, WITHOUT importing torch.  GSMCAL_HIP_RUNTIME=system keeps the system runtime."""
+    import sys
+    if os.environ.get("GSMCAL_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return                                   # a runtime is already mapped: whichever it is, it is the one
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 - best effort: without it the process just must import torch before gsmcal
+        pass
+
+
 def load(build_if_missing=True):
     """Load libgsmcal.so and attach prototypes.  Raises GsmcalError if it is absent and cannot be built:
     there is no CPU fallback in this package."""
@@ -128,6 +152,7 @@ def load(build_if_missing=True):
             _build.build()
         except Exception as e:  # noqa: BLE001
             raise GsmcalError(f"libgsmcal.so is missing and could not be built: {e}") from e
+    _share_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the header and the library disagree

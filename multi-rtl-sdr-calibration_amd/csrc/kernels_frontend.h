@@ -924,8 +924,8 @@ __host__ __device__ inline size_t stream_tile_lds(int ntaps) {
     const size_t xs_n = span + span / 4 + 16;                     // padded complex input
     const size_t buf = 1024 + 16;
     // buf0 | region1 = max(xs, buf1) | coef | raw ushorts | rotator tables 2 x (2 + 34 + 32)
-    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * 8 + ((span + 7) & ~(size_t)7) * 2 +
-           2 * 68 * sizeof(cplx);
+    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + (size_t)((ntaps + 7) & ~3) * 8 + ((span + 7) & ~(size_t)7) * 2 +
+           2 * (68 + 34) * sizeof(cplx);     // (taps padded to a multiple of four; per derotation S|A|B and the tile's S*A[q])
 }
 
 // T[0], T[1] = S of the current / next tile, T[2..35] = A[0..33], T[36..67] = B[0..31]
@@ -976,14 +976,17 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
     cplx* buf0 = (cplx*)smem;                                   // level 0 (FIR output)
     cplx* buf1 = buf0 + bufn;                                   // level 2 (after lerp + derotation); aliases xs
     cplx* xs = buf1;
-    double* c_s = (double*)(buf1 + (xs_n > bufn ? xs_n : bufn));
-    unsigned short* r_s = (unsigned short*)(c_s + ((ntp + 1) & ~1));
+    double* c_s = (double*)(buf1 + (xs_n > bufn ? xs_n : bufn));   // rev[j] = coef[ntp-1-j] (oldest tap first), zero-padded to ntp4
+    const int ntp4 = (ntp + 3) & ~3;
+    unsigned short* r_s = (unsigned short*)(c_s + ((ntp + 7) & ~3));
     cplx* T2 = (cplx*)(r_s + ((span_max + 7) & ~(size_t)7));
     cplx* T4 = T2 + 68;
+    cplx* SA2 = T4 + 68;                                        // S*A[q] of the current tile, q < 34, per derotation
+    cplx* SA4 = SA2 + 34;
     const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
     const long ao = (long)(((uintptr_t)base >> 1) & 7);         // samples past a 16-byte boundary at g = 0
     // ---- once per workgroup: taps, the stream's A/B rotator tables, the first tile's S and raw bytes ----
-    for (int i = tid; i < ntp; i += ST_THREADS) c_s[i] = a.coef[i];
+    for (int i = tid; i < ntp4; i += ST_THREADS) c_s[i] = i < ntp ? a.coef[ntp - 1 - i] : 0.0;
     StRange rg = st_range(tile, nq, n0, ln[2], f1, f3);
     if (tid >= 64 && tid < 64 + 2 * 66) {                       // A[j] = exp(1i*fl(32j*c)), B[m] = exp(1i*fl(m*c)) for both derotations
         const int i = (tid - 64) % 66, which = (tid - 64) / 66;
@@ -1005,7 +1008,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
         const long lo0 = rg.lo0, lo2 = rg.lo2, lo3 = rg.lo3;
         {   // raw2iq.m:6-8 on the staged span
             const int span = cnt0 + ntp - 1, off = (int)(first - first_al);
-            for (int i = tid; i < span + 8; i += ST_THREADS) {
+            for (int i = tid; i < span + 12; i += ST_THREADS) {       // (+12: finite zeros behind the span for the padding taps)
                 const long g = first + i;
                 cplx v = make_double2(0.0, 0.0);
                 if (i < span && g >= 0 && g < n0) {
@@ -1043,6 +1046,9 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
         }
         // ---- pass 1: filter(coef,1,.) -> buf0, four consecutive outputs per lane, oldest tap first (gather_core's loop).
         // (Two outputs per lane with twice the threads ran 40 % slower: the LDS reads per FMA double.) ----
+        // The taps sit in LDS reversed and zero-padded to a multiple of four: no remainder loop (fma(0, x, acc) = acc for the
+        // finite samples staged behind the span, so the sums are those of the ntp-term loop bit for bit), and two trips per
+        // iteration let the sliding window rotate by renaming instead of eight register moves per trip.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * ST_THREADS) {
             double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
             cplx w0 = xs[xs_pad(i0)], w1 = xs[xs_pad(i0 + 1)], w2 = xs[xs_pad(i0 + 2)], w3 = xs[xs_pad(i0 + 3)];
@@ -1051,24 +1057,16 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
             ar1 = fma(C, B.x, ar1); ai1 = fma(C, B.y, ai1);         \
             ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);         \
             ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
-            int t = 0;
-            for (; t + 4 <= ntp; t += 4) {
+#pragma unroll 2
+            for (int t = 0; t < ntp4; t += 4) {
                 const cplx* nxs = xs + xs_pad(i0 + t + 4);
                 const cplx n0s = nxs[0], n1s = nxs[1], n2s = nxs[2], n3s = nxs[3];
-                const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2_ = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];
+                const double c0 = c_s[t], c1 = c_s[t + 1], c2_ = c_s[t + 2], c3 = c_s[t + 3];
                 ST_FIR_TAP(c0, w0, w1, w2, w3)
                 ST_FIR_TAP(c1, w1, w2, w3, n0s)
                 ST_FIR_TAP(c2_, w2, w3, n0s, n1s)
                 ST_FIR_TAP(c3, w3, n0s, n1s, n2s)
                 w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
-            }
-            int p = i0 + t + 3;
-            for (; t < ntp; ++t) {
-                const double c = c_s[ntp - 1 - t];
-                ST_FIR_TAP(c, w0, w1, w2, w3)
-                w0 = w1; w1 = w2; w2 = w3;
-                ++p;
-                w3 = xs[xs_pad(p)];
             }
 #undef ST_FIR_TAP
             buf0[i0] = make_double2(ar0, ai0);
@@ -1094,6 +1092,13 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
                 (tid == ST_THREADS - 1 ? T4 : T2)[sidx ^ 1] = make_double2(cs, sn);
             }
         }
+        // S * A[q] of this tile for both derotations (34 + 34 products), so that a sample's rotator is one product, SA[m>>5]*B[m&31]:
+        // the same three factors as st_rot(), associated the same way ((S*A)*B), bit-identical
+        if (tid >= 128 && tid < 128 + 68) {
+            const int q = (tid - 128) % 34, which = (tid - 128) / 34;
+            const cplx* T = which ? T4 : T2;
+            (which ? SA4 : SA2)[q] = cmul(T[sidx], T[2 + q]);
+        }
         __syncthreads();                                        // (xs is dead: buf1 may be written)
         // ---- pass 2: level 1 = interp1 (FCCH_fine_correction.m:123-125), level 2 = .* exp(1i*k*c2) (:165) -> buf1 ----
         {
@@ -1107,7 +1112,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
                 const double t = xq - j0f;
                 const cplx v0 = buf0[j0], v1 = buf0[j1];
                 const cplx v = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
-                buf1[i] = cmul(v, st_rot(T2, sidx, i));
+                buf1[i] = cmul(v, cmul(SA2[i >> 5], T2[36 + (i & 31)]));
             }
         }
         __syncthreads();
@@ -1125,7 +1130,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
                 const double t = xq - j0f;
                 const cplx v0 = buf1[j0], v1 = buf1[j1];
                 const cplx v = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
-                dst[i] = cmul(v, st_rot(T4, sidx, i));
+                dst[i] = cmul(v, cmul(SA4[i >> 5], T4[36 + (i & 31)]));
             }
         }
         __syncthreads();                                        // buf1 (= xs) and the tables' S slot may be rewritten

@@ -744,3 +744,15 @@ def test_multi_lane_graph_replay_of_a_256_stream_batch(g, ctx, setup):
         for i in range(8, D):                                # every copy of a stream, whichever lane it ran on
             assert np.array_equal(table[i], table[i % 8], equal_nan=True), f"call {call}, stream {i}"
             assert np.array_equal(pos[i], pos[i % 8]), f"call {call}, stream {i}"
+
+
+def test_gsmcal_before_torch_in_one_process():
+    """Two HIP runtimes cannot share a process: libgsmcal.so loaded first used to map the system libamdhip64 and a later
+    `import torch` (which bundles its own) then found "No HIP GPUs" -- whether a test passed depended on which module had
+    been imported first.  _lib.load() now maps the PyTorch wheel's runtime first when one is installed; checked in a fresh
+    process, gsmcal first, then torch on the same GPU."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "order_check.py"), "gsmcal_first"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "torch cuda ok" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("libamdhip64") == 1, r.stdout          # one HIP runtime mapped
