@@ -831,8 +831,9 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
             cplx y0, y1, y2, y3;
+            // (the run-time-count form: the two-trip form of fir4_lds<47> needs ~20 more registers than the 80 the fused
+            // per-burst kernels have -- scratch in the loop; k_fine_cert, at 108 registers, uses it)
             if (compact) fir4_lds<0, false>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
-            else if (ntp == 47) fir4_lds<47>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             else fir4_lds<0>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             out0[i0] = y0;
             if (i0 + 1 < cnt0) out0[i0 + 1] = y1;
