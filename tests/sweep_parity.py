@@ -1,5 +1,6 @@
 """Randomised parity sweep (not collected by pytest): N seeded streams through the HIP batch path and the
-oracle; prints mismatches.  Usage: python tests/sweep_parity.py [n_streams] [first_dongle] [frames]"""
+oracle; prints mismatches.  Usage: python tests/sweep_parity.py [n_streams] [first_dongle] [frames] [batch]
+(batch: streams per gsmcal_calibrate_batch call, default all at once; 64 keeps every call on the fused k_post_chain_r path)"""
 import os
 import sys
 import time
@@ -37,6 +38,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 102
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else n
     import gsmcal
     import parity
     synth = gsmcal.synth
@@ -62,23 +64,27 @@ def main():
         raw = np.stack(list(ex.map(_gen_one, jobs, chunksize=2)))
         res = list(ex.map(_oracle_one, jobs, chunksize=2))
     t1 = time.time()
-    out = gsmcal.calibrate_batch(raw, coef, ts, FC)
-    det = gsmcal.last_batch_details(n)
     bad = 0
     n_ok = 0
-    for i, (d, orc, err) in enumerate(res):
-        if orc is None:
-            if out["table"][i, 9] >= 0:
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        out = gsmcal.calibrate_batch(raw[lo:hi], coef, ts, FC)
+        det = gsmcal.last_batch_details(hi - lo)
+        for i in range(lo, hi):
+            d, orc, err = res[i]
+            k = i - lo
+            if orc is None:
+                if out["table"][k, 9] >= 0:
+                    bad += 1
+                    print(f"stream {d}: oracle raised '{err}' but gpu status {out['table'][k, 9]}")
+                continue
+            try:
+                parity.compare_stream(orc, out["table"][k], det, k, out["pos_info"][k])
+                n_ok += out["table"][k, 9] == 0
+            except AssertionError as e:
                 bad += 1
-                print(f"stream {d}: oracle raised '{err}' but gpu status {out['table'][i, 9]}")
-            continue
-        try:
-            parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
-            n_ok += out["table"][i, 9] == 0
-        except AssertionError as e:
-            bad += 1
-            print(f"stream {d} {kws[i]}: MISMATCH {e}")
-    print(f"sweep: {n} streams from dongle {first}, {n_ok} calibrated, {bad} mismatches; gen+oracle {t1 - t0:.1f}s gpu {time.time() - t1:.1f}s")
+                print(f"stream {d} {kws[i]}: MISMATCH {e}")
+    print(f"sweep: {n} streams from dongle {first} in batches of {batch}, {n_ok} calibrated, {bad} mismatches; gen+oracle {t1 - t0:.1f}s gpu {time.time() - t1:.1f}s")
     return 1 if bad else 0
 
 
