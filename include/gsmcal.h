@@ -309,6 +309,13 @@ int gsmcal_synth_expand_dev(gsmcal_ctx* ctx, const uint8_t* d_base, int k, long 
 int gsmcal_last_batch_details(gsmcal_ctx* ctx, int d, double* coarse_pos, double* coarse_snr,
                               double* fine_first, double* fcch_pos, double* sch_first, int* counts);
 
+/* Parity tap: the per-window SNR table (move_fft_snr_runtime_avg.m:18-27, 1-based window i at index i-1) the coarse detector of
+ * the last batch call built for `stream`.  *n_moving entries are the moving search's windows (every one computed in full);
+ * entries beyond them (latency path only, up to *n_table) serve the hop walk and hold -inf where a window was proved to be
+ * below the screening level.  The decisions snr - avg > th are taken on these values: the parity suite measures how far they
+ * sit from the oracle's (the implementation noise the certified scan's 1e-6 dB margin has to cover). */
+int gsmcal_last_batch_snr(gsmcal_ctx* ctx, int stream, double* snr, long cap, long* n_table, long* n_moving);
+
 #ifdef __cplusplus
 }
 #endif

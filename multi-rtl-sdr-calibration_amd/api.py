@@ -423,6 +423,16 @@ def synth_expand_dev(d_base, k, n, d_out, d, first_unit=0, seed=20260101, ctx=No
                                               int(first_unit), int(seed)), "synth_expand_dev")
 
 
+def last_batch_snr(stream, ctx=None):
+    """Parity tap: (snr table of `stream` from the last batch call, number of moving-search windows at its head)."""
+    ctx = ctx or default_context()
+    buf = np.zeros(1 << 16)
+    n_tab, n_mov = C.c_long(0), C.c_long(0)
+    ctx.check(ctx.lib.gsmcal_last_batch_snr(ctx.h, int(stream), _dp(buf), len(buf), C.byref(n_tab), C.byref(n_mov)),
+              "last_batch_snr")
+    return buf[: min(n_tab.value, len(buf))].copy(), int(n_mov.value)
+
+
 def last_batch_details(d, ctx=None):
     """Intermediates of the last batch call (coarse/fine/SCH positions per stream) for parity tests."""
     ctx = ctx or default_context()

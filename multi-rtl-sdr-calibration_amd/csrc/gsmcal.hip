@@ -56,6 +56,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
+    long snr_stride = 0, snr_nmove = 0; // SNR table of the last coarse(): entries per stream, and how many of them are the moving search's
     int xch_S = 0, xch_H = 0;          // geometry the exchange block / launch counters of k_post_chain_r were cleared for
     int win_l0_len = 0, win_l0_H = 0;  // > 0: `win` holds the fine search's level-0 windows (this length each, H per stream) of the call in progress
 };
@@ -698,6 +699,7 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     }
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * ntab * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = ntab;
+    c->cur->snr_stride = ntab; c->cur->snr_nmove = nwin;
     const dim3 sgrid(sblocks, S);
     if (fft_len == 16 && a.snr_nwin > 0) LAUNCH(c, (k_coarse_snr<true, true>), sgrid, dim3(CS_SNR_THREADS), 0, a);
     else if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, sgrid, dim3(256), 0, a);
@@ -1924,6 +1926,22 @@ int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* 
         }
     }
     return 0;
+}
+
+int gsmcal_last_batch_snr(gsmcal_ctx* c, int stream, double* snr, long cap, long* n_table, long* n_moving) {
+    if (!c || stream < 0 || stream >= c->last_S || !snr || cap < 1) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n_lanes_used; ++i) {
+        const Lane& L = c->lanes[i];
+        if (stream < L.lo || stream >= L.lo + L.n || !L.snrbuf.p || L.snr_stride <= 0) continue;
+        const long n = L.snr_stride < cap ? L.snr_stride : cap;
+        HIPCHK(c, hipMemcpy(snr, (const double*)L.snrbuf.p + (size_t)(stream - L.lo) * L.snr_stride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        if (n_table) *n_table = L.snr_stride;
+        if (n_moving) *n_moving = L.snr_nmove;
+        return 0;
+    }
+    return GSMCAL_E_ARG;
 }
 
 #ifdef GSMCAL_DEVTIMING
