@@ -453,6 +453,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     // (999 while the history still holds its seed, move_fft_snr_runtime_avg.m:11), S[mv_len+q] is
     // window q's own SNR; every load of the unrolled recurrence below is unconditional.  The global loads go out
     // first, 16 per lane in flight, and everything else of the prologue runs under their latency.
+    // the front kernel's partial byte sums (the stream's mean): requested by the first wave BEFORE the table loads below, so
+    // that the two round trips to L2 overlap; summed after them
+    unsigned long long pvi[4] = {0, 0, 0, 0}, pvq[4] = {0, 0, 0, 0};
+    const bool pre_mean = a.mean_corr && a.npartial <= 256;
+    if (pre_mean && tid < 64) {
+        const unsigned long long* pp = a.partial + (size_t)blockIdx.x * a.npartial * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = tid + 64 * k;
+            if (b < a.npartial) { pvi[k] = pp[2 * b]; pvq[k] = pp[2 * b + 1]; }
+        }
+    }
     if (!bad && a.mode != 2) {
         const double* sg = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
         const long tot = mv_len + g.nwin + 64;
@@ -472,7 +484,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     }
     double mr0 = 0.0, mi0 = 0.0;
     unsigned long long ti0 = 0, tq0 = 0;
-    if (a.mean_corr) stream_mean(a, blockIdx.x, &mr0, &mi0, &ti0, &tq0);      // batch path: means from the front kernel
+    if (pre_mean) {                                                           // batch path: means from the front kernel
+        __shared__ unsigned long long sh_tot2[2];
+        if (tid < 64) {
+            unsigned long long si = (pvi[0] + pvi[1]) + (pvi[2] + pvi[3]), sq = (pvq[0] + pvq[1]) + (pvq[2] + pvq[3]);   // (integers: any order)
+            for (int off = 32; off > 0; off >>= 1) {
+                si += __shfl_down(si, off, 64);
+                sq += __shfl_down(sq, off, 64);
+            }
+            if (tid == 0) { sh_tot2[0] = si; sh_tot2[1] = sq; }
+        }
+        __syncthreads();
+        ti0 = sh_tot2[0]; tq0 = sh_tot2[1];
+        mr0 = (double)ti0 / (double)a.n0;
+        mi0 = (double)tq0 / (double)a.n0;
+    } else if (a.mean_corr) stream_mean(a, blockIdx.x, &mr0, &mi0, &ti0, &tq0);
     const DecView s = dec_view(a, blockIdx.x, a.mean_corr ? mr0 : st_g->mean_re, a.mean_corr ? mi0 : st_g->mean_im);
     if (a.mean_corr) {
         // batch path: this kernel is the first to touch the stream's state -- build it from scratch in LDS (all zero,
