@@ -427,8 +427,10 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             // only while every workgroup of the launch is resident at once (three 512-thread workgroups per CU): a workgroup
             // waiting at a stream barrier holds its slot, which costs nothing in the latency regime (64 streams: 0.234 vs
             // 0.237 ms per step) and a fifth of the throughput beyond it (256 streams: 0.73 vs 0.63 ms; 1024: 2.53 vs 2.13)
+            // (and only for a call that runs on ONE lane: four lanes of 64 streams each would put 3 072 waiting workgroups on
+            // 768 slots -- measured 0.70 against 0.63 ms at 256 streams)
             chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && lds <= 52 * 1024 &&
-                           (long)H * S <= 3L * c->n_cu;
+                           (long)H * S <= 3L * c->n_cu && c->n_lanes_used == 1;
             if (chain->fused) {
                 const size_t need = (size_t)2 * S * sizeof(unsigned);
                 if (c->cur->postctr.cap < need) {
