@@ -786,3 +786,23 @@ def test_snr_values_of_the_decision_path_sit_far_inside_the_certificate_margin(g
         assert np.all(want[~computed] < 5.0)
         assert np.mean(~computed[n_mov:]) > 0.5                  # and most later windows are
     assert worst < 1e-10, f"largest SNR difference {worst:.3e} dB"  # measured: <= 1.6e-12 dB (median 1.5e-15), six orders inside the 1e-6 dB margin
+
+
+def test_per_stream_carrier_frequencies_in_one_batch(g, setup):
+    """carrier_freq is an argument of FCCH_fine_correction / carrier_correct_post_SCH (gsm_sync_demod.m:14 passes the tuned
+    frequency): dongles of one batch may sit on different ARFCNs.  Each stream's carrier ppm must be computed with ITS
+    frequency -- in the fused tail (<= 64 streams on one lane) and in the multi-lane plan (130 streams: two lanes, the second
+    one starting in the middle of the frequency array)."""
+    fcs = np.array([935.2e6, 947.6e6, 957.4e6, 959.8e6])
+    distinct = [g.synth.make_stream(dongle=600 + i, carrier_freq=fcs[i])[0] for i in range(4)]
+    orc = [o.calibrate_stream(distinct[i], setup["coef"], setup["ts"], fcs[i]) for i in range(4)]
+    assert sum(np.isfinite(x["total_carrier_ppm"]) for x in orc) >= 2
+    for D in (4, 130):
+        raw = np.stack([distinct[i % 4] for i in range(D)])
+        cf = np.array([fcs[i % 4] for i in range(D)])
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], cf)
+        det = g.last_batch_details(min(D, 8))
+        for i in range(min(D, 8)):
+            parity.compare_stream(orc[i % 4], out["table"][i], det, i, out["pos_info"][i])
+        for i in range(D):
+            assert np.array_equal(out["table"][i], out["table"][i % 4], equal_nan=True), (D, i)
