@@ -1666,7 +1666,24 @@ struct RcclApi {
 static RcclApi* rccl_api() {
     static RcclApi api;
     if (api.h) return &api;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must belong to the HIP runtime this process runs on: a process whose runtime is the copy bundled with a
+    // PyTorch-ROCm wheel and whose RCCL is the system one works until exit and then aborts in the allocator (double free).
+    // So: a librccl that is mapped already; else the one lying beside the loaded libamdhip64; else the loader's choice.
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) {
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t cut = dir.rfind('/');
+            if (cut != std::string::npos) {
+                dir.resize(cut + 1);
+                h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            }
+        }
+    }
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return nullptr;

@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void fft37_step1(const cplx* xs, cplx* B, const cplx*
         const int k1 = o / N2, n2 = o - k1 * N2;
         double ar = 0.0, ai = 0.0;
         int idx = 0;
-#pragma unroll
+#pragma unroll 4                     // (the fallback of a fallback: unrolled completely it costs its callers 60 registers)
         for (int n1 = 0; n1 < 37; ++n1) {
             const cplx v = xs[N2 * n1 + n2], t = w37[idx];
             ar = fma(v.x, t.x, fma(-v.y, t.y, ar));
@@ -1021,13 +1021,19 @@ __device__ __forceinline__ void fft37_step1(const cplx* xs, cplx* B, const cplx*
 //   Y[37-p] = the same two sums with +i:  one pass yields both outputs, with 2 real MACs where the direct form has 8.
 // Pass A rewrites xs in place (rows 1..18 <- sums, rows 36..19 <- differences), pass B takes one (n2, p) per thread.
 // Same mathematics as fft37_step1, different summation order (fp64: ~1e-16 relative).  Contains a barrier.
+// pre(n, v): applied to sample n as it is first read (pass A; row 0, which pass A does not touch, is rewritten too) --
+// a rotation the caller would otherwise spend a pass over xs and a barrier on.
+struct Fft37NoPre { __device__ __forceinline__ cplx operator()(int, const cplx& v) const { return v; } };
+template <bool PRE = false, class F = Fft37NoPre>
 __device__ __forceinline__ void fft37_step1_sym(cplx* xs, cplx* B, const cplx* w37, const cplx* __restrict__ tw_g,
-                                                int nfft, int N2, int ldb, int tid, int nthreads) {
-    for (int o = tid; o < 18 * N2; o += nthreads) {
+                                                int nfft, int N2, int ldb, int tid, int nthreads, F pre = F()) {
+    for (int o = tid; o < (PRE ? 19 : 18) * N2; o += nthreads) {
+        if (PRE && o >= 18 * N2) { const int n2 = o - 18 * N2; xs[n2] = pre(n2, xs[n2]); continue; }
         const int n1 = 1 + o / N2, n2 = o - (n1 - 1) * N2;
-        const cplx u = xs[N2 * n1 + n2], v = xs[N2 * (37 - n1) + n2];
-        xs[N2 * n1 + n2] = make_double2(u.x + v.x, u.y + v.y);
-        xs[N2 * (37 - n1) + n2] = make_double2(u.x - v.x, u.y - v.y);
+        const int ia = N2 * n1 + n2, ib = N2 * (37 - n1) + n2;
+        const cplx u = PRE ? pre(ia, xs[ia]) : xs[ia], v = PRE ? pre(ib, xs[ib]) : xs[ib];
+        xs[ia] = make_double2(u.x + v.x, u.y + v.y);
+        xs[ib] = make_double2(u.x - v.x, u.y - v.y);
     }
     __syncthreads();
     for (int o = tid; o < 19 * N2; o += nthreads) {
@@ -1206,22 +1212,25 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_burst(const StreamState* __
 // X_k at one shift by a direct fp64 DFT over the nfft samples xw[0..nfft), executed by one wave: lane l sums
 // the terms n = l, l+64, ... (fixed order), then a shuffle tree adds the 64 partials.  The 19 table loads of a
 // pass are independent and issued together (the twiddle table lives in L2).  Returns the value in every lane.
+// NB: table loads in flight per pass (the order of the additions does not depend on it).  19 = the whole 8x-oversampled
+// window in one pass, 76 registers; k_post_chain_r, at 80 registers for everything, takes 6.
+template <int NB = 19>
 __device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __restrict__ tw_g, int nfft, int lane) {
     double ar = 0.0, ai = 0.0;
     const int stp = (int)(((unsigned)k * 64u) % (unsigned)nfft);          // (k < nfft <= 2^24: no overflow)
     int idx = (int)(((unsigned)k * (unsigned)lane) % (unsigned)nfft);
-    for (int n0 = 0; n0 < nfft; n0 += 19 * 64) {
-        cplx t[19];
+    for (int n0 = 0; n0 < nfft; n0 += NB * 64) {
+        cplx t[NB];
         int id = idx;
 #pragma unroll
-        for (int u = 0; u < 19; ++u) {
+        for (int u = 0; u < NB; ++u) {
             t[u] = tw_g[id];
             id += stp;
             if (id >= nfft) id -= nfft;
         }
         idx = id;
 #pragma unroll
-        for (int u = 0; u < 19; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const int n = n0 + lane + 64 * u;
             if (n < nfft) {
                 const cplx v = xw[n];
@@ -1426,7 +1435,7 @@ __device__ __forceinline__ void peak_store(PeakOut* dst, const PeakOut& o) {
     __hip_atomic_store(d + 1, (unsigned long long)(unsigned)o.tie | ((unsigned long long)(unsigned)o.k << 32), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int FVT>
+template <int FVT, int ANB = 19>
 __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__ sts,
                                                  const cplx* __restrict__ win, long win_stream_stride,
                                                  long win_stride, int nshift, int nfft,
@@ -1517,7 +1526,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
             for (int i = wave; i < ni; i += FVT / 64) {
                 const int k = items[i] >> 8, c = items[i] & 0xFF;
                 const int t0 = c * FS_CHUNK;
-                const cplx av = anchor_dft(xs + t0, k, tw_g, nfft, lane);
+                const cplx av = anchor_dft<ANB>(xs + t0, k, tw_g, nfft, lane);
                 const double a0r = av.x, a0i = av.y;
                 const int lim = nstep - t0 < FS_CHUNK ? nstep - t0 : FS_CHUNK;
                 double sr = 0.0, si = 0.0;

@@ -62,11 +62,146 @@ __device__ __forceinline__ PeakOut merge_peaks_coherent(const PeakOut* p, int NB
 // holds B[37][N2+1]; w37 | wN2 | P[2*hnl] follow the carve.  ~48 KB: three workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define BT_THREADS 512
+
+// ------------------------------------------------------------------------------------------------
+// burst_gather_fast: gather_core for the case k_post_chain_r's burst stages nearly always see -- the stream's state is
+// this workgroup's LDS copy, level 0 of the burst lies inside a window the fine search filtered (a.l0), and the chain
+// above it is LERP (level 1) or LERP | MIX | LERP-or-COPY (level 3).  Same arithmetic per sample as gather_core (same
+// expressions in the same order: the two give identical bits), organised around what bounds a workgroup here, the
+// number of barrier-separated phases and of round trips to L2:
+//   * every wave works the plan out itself from LDS (no plan phase);
+//   * level 1 is interpolated straight from the window buffer (no LDS copy of level 0), with the loads of the burst
+//     stage's nfft-point twiddle table in flight at the same time;
+//   * level 3: the MIX rotator is applied to the two level-1 samples of each level-3 output as they are read (no level-2
+//     buffer) -- two phases where gather_core has six.
+// Returns 1: window in smem (buf0), twiddle table in the other buffer, NO trailing barrier; 0: not this case (the caller
+// falls back to gather_core); -1: this workgroup has no window.  All three block-uniform.
+// ------------------------------------------------------------------------------------------------
+// a wave-uniform value (read from LDS, so in a vector register as far as the compiler knows) moved to scalar registers
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni_l(long v) {
+    return (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)v >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+__device__ __forceinline__ double uni_d(double v) { return __longlong_as_double(uni_l(__double_as_longlong(v))); }
+template <int NT, int KID = -1>
+__device__ __forceinline__ int burst_gather_fast(const StreamState* __restrict__ st, const GatherArgs& a, unsigned char* smem,
+                                                 int widx, int s, const cplx* __restrict__ tw_g, int nfft) {
+    const int tid = threadIdx.x, level = a.level;
+    if (!a.l0 || a.src_kind != SRC_RAW || a.tiles || (level != 1 && level != 3) || nfft > 3 * NT || nfft > a.len + 40) return 0;
+    if (widx >= MAXH) return -1;
+    // every field of the plan in one batch of LDS reads (the generic pointer is this workgroup's LDS copy: addressed as
+    // LDS the reads are ds_read, not flat loads that take the vector-memory path to find that out), decisions afterwards
+    typedef const __attribute__((address_space(3))) StreamState* LdsState;
+    LdsState sl = (LdsState)st;
+    const int lane = tid & 63;
+    const int v_nwin = sl->n_win, v_t1 = sl->op[1].type, v_t2 = sl->op[2].type, v_t3 = sl->op[3].type, v_nf = sl->n_fine_ws;
+    const double v_f1 = sl->op[1].param, v_c2 = sl->op[2].param, v_f3 = sl->op[3].param;
+    const long v_ws = sl->win_start[widx], v_n2 = sl->op[2].n, v_n0 = sl->n0;
+    const long fw = lane < MAXH ? sl->fine_ws[lane] : 0;
+    if (widx >= uni_i(v_nwin)) return -1;
+    if (uni_i(v_t1) != OP_LERP) return 0;
+    const double f1 = uni_d(v_f1);
+    int t3 = OP_NONE;
+    double c2 = 0.0, f3 = 1.0;
+    if (level == 3) {
+        t3 = uni_i(v_t3);
+        if (uni_i(v_t2) != OP_MIX || (t3 != OP_LERP && t3 != OP_COPY)) return 0;
+        c2 = uni_d(v_c2);
+        f3 = uni_d(v_f3);
+    }
+    const int L = a.len;
+    const long lo3 = uni_l(v_ws), hi3 = lo3 + L - 1;
+    long lo1 = lo3, hi1 = hi3;                                   // level 1 (and 2: a MIX keeps the range)
+    if (level == 3 && t3 == OP_LERP) {
+        lo1 = (long)floor((double)lo3 * f3);
+        const long h = (long)floor((double)hi3 * f3) + 1, n2 = uni_l(v_n2);
+        hi1 = h > n2 - 1 ? n2 - 1 : h;
+    }
+    const long lo0 = (long)floor((double)lo1 * f1);
+    long hi0 = (long)floor((double)hi1 * f1) + 1;
+    {
+        const long n0 = uni_l(v_n0);
+        hi0 = hi0 > n0 - 1 ? n0 - 1 : hi0;
+    }
+    const int cnt1 = (int)(hi1 - lo1 + 1);
+    const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true, a.pad != 0);
+    if (level == 3 && (cnt1 > 32 * GC_ROT_A || cnt1 > (int)gc.bufn || cnt1 <= 0)) return 0;
+    // the fine window holding [lo0, hi0] (every wave finds it itself)
+    int h0;
+    long off0;
+    {
+        const bool in = lane < uni_i(v_nf) && lane < MAXH;
+        const unsigned long long m = __ballot(in && fw <= lo0 && hi0 < fw + a.l0_len);
+        if (!m) return 0;
+        h0 = __ffsll((long long)m) - 1;
+        off0 = lo0 - uni_l(__shfl(fw, h0, 64));
+    }
+    const cplx* __restrict__ x = a.l0 + (size_t)s * a.l0_stream_stride + (size_t)h0 * a.l0_win_stride + off0;   // x[i]: level-0 sample lo0+i
+    cplx* buf0 = (cplx*)smem;
+    cplx* buf1 = (cplx*)(smem + gc.off_region1);
+    auto lerp1 = [&](int i) {                                    // level-1 sample lo1+i
+        const long k = lo1 + i;
+        const double xq = (double)k * f1;                        // interp_seq = (0:max_len-1)'.*(1+e)
+        const long i0 = (long)floor(xq);
+        const long i1 = i0 + 1 > hi0 ? hi0 : i0 + 1;             // beyond the last sample the weight is 0
+        const double t = xq - (double)i0;
+        const cplx v0 = x[i0 - lo0], v1 = x[i1 - lo0];
+        return make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
+    };
+    DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, 5);
+    if (level == 1) {
+        for (int n = tid; n < nfft; n += NT) buf1[n] = tw_g[n];
+        DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, 6);
+        for (int i = tid; i < L; i += NT) buf0[i] = lerp1(i);
+        return 1;
+    }
+    // level 3
+    cplx* T = (cplx*)(smem + gc.off_rot);                        // S | A[] | B[] of the level-2 rotator (gather_core's table)
+    const int na = (cnt1 + 31) >> 5;
+    for (int i = tid; i < cnt1; i += NT) buf1[i] = lerp1(i);
+    for (int i = tid; i < 1 + na + 32; i += NT) {
+        const double arg = i == 0 ? (double)lo1 * c2 : (i <= na ? (double)(32 * (i - 1)) * c2 : (double)(i - 1 - na) * c2);
+        double sn, cs;
+        sincos_large(arg, &sn, &cs);
+        T[i == 0 ? 0 : (i <= na ? i : 1 + GC_ROT_A + (i - 1 - na))] = make_double2(cs, sn);
+    }
+    DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, 6);
+    __syncthreads();
+    DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, 7);
+    // the burst stage's twiddle table goes where level 1 is now: loaded here, stored after the barrier below.  (Clamped
+    // unconditional loads: with the three loads predicated the register allocator spills 150 vector registers to scratch,
+    // 880 B/lane, and a frame that size halves the speed of every kernel on the queue.)
+    const cplx tw0 = tw_g[min(tid, nfft - 1)], tw1 = tw_g[min(tid + NT, nfft - 1)], tw2 = tw_g[min(tid + 2 * NT, nfft - 1)];
+    auto lvl2 = [&](int i) {                                     // level-2 sample lo1+i: exp(1i*k*comp_phase_rotate) from the table
+        return cmul(buf1[i], cmul(cmul(T[0], T[1 + (i >> 5)]), T[1 + GC_ROT_A + (i & 31)]));
+    };
+    if (t3 == OP_LERP) {
+#pragma unroll 1
+        for (int i = tid; i < L; i += NT) {
+            const long k = lo3 + i;
+            const double xq = (double)k * f3;
+            const long i0 = (long)floor(xq);
+            const long i1 = i0 + 1 > hi1 ? hi1 : i0 + 1;
+            const double t = xq - (double)i0;
+            const cplx v0 = lvl2((int)(i0 - lo1)), v1 = lvl2((int)(i1 - lo1));
+            buf0[i] = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
+        }
+    } else {
+        for (int i = tid; i < L; i += NT) buf0[i] = lvl2(i);
+    }
+    __syncthreads();                                             // level 1 is dead
+    if (tid < nfft) buf1[tid] = tw0;
+    if (tid + NT < nfft) buf1[tid + NT] = tw1;
+    if (tid + 2 * NT < nfft) buf1[tid + 2 * NT] = tw2;
+    return 1;
+}
 #define BT_STAMP(i) DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, i)
 template <int GATE>
 __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, const GatherArgs& a, int nfft,
                                                 const cplx* __restrict__ tw_g, int ov, int prior_mode,
-                                                unsigned char* smem, double* res = nullptr) {   // res: {fo, snr} instead of the stores into the state
+                                                unsigned char* smem, double* res = nullptr,    // res: {fo, snr} instead of the stores into the state
+                                                bool state_in_lds = false) {                   // sts + blockIdx.y is this workgroup's LDS copy
     __shared__ double red_p[BT_THREADS / 64];
     __shared__ int red_t[BT_THREADS / 64];
     __shared__ double red[2 * (BT_THREADS / 64)];
@@ -74,9 +209,14 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     __shared__ int sh_key;
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     BT_STAMP(0);
-    cplx* xs = gather_core<BT_THREADS, GATE ? KID_BT1 : KID_BT0>(sts, a, smem, w, s, true);   // nfft samples of the burst, in LDS
-    if (!xs) return;                                                // block-uniform
-    __syncthreads();
+    const int fast = state_in_lds ? burst_gather_fast<BT_THREADS, GATE ? KID_BT1 : KID_BT0>(sts + s, a, smem, w, s, tw_g, nfft) : 0;
+    if (fast < 0) return;                                           // block-uniform, like the two below
+    cplx* xs = (cplx*)smem;                                         // nfft samples of the burst, in LDS
+    if (!fast) {
+        xs = gather_core<BT_THREADS, GATE ? KID_BT1 : KID_BT0>(sts, a, smem, w, s, true);
+        if (!xs) return;
+        __syncthreads();
+    }
     BT_STAMP(1);
     StreamState* st = sts + s;
     const int N2 = nfft / 37, ldb = N2 + 1;
@@ -89,7 +229,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     // the nfft-point twiddle table, staged in the idle buffer B until B is needed (the candidate DFTs and the rotation
     // below index it data-dependently: from global memory every step of those loops was a round trip to L2)
     cplx* twl = B;
-    for (int n = tid; n < nfft; n += BT_THREADS) twl[n] = tw_g[n];
+    if (!fast) for (int n = tid; n < nfft; n += BT_THREADS) twl[n] = tw_g[n];
     fft37_tables(w37, wN2, N2, tid, tw_g);
     __syncthreads();
     // ---- spectrum argmax, first max in fftshift order (:149-150) ----
@@ -171,34 +311,33 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     const double sampling_rate = GSM_SYMBOL_RATE * (double)ov;
     // :151  int_phase_rotate = 2.*pi.*(max_idx - ((fft_len/2)+1))./fft_len
     const double ipr = (TWO_PI_D * (double)(max_idx - (nfft / 2 + 1))) / (double)nfft;
-    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate)   (in place).  int_phase_rotate is an
+    // :152  fcch_mat .* exp(-1i.*((0:fft_len-1)')*int_phase_rotate).  int_phase_rotate is an
     // integer number of bins j, so exp(-1i*n*ipr) = exp(-2*pi*i*(n*j mod N)/N): taken from the exact table
     // (the reference's fl(n*ipr) differs from it by < 1e-12 rad, far below what the estimator resolves).
-    {
-        const int jb = max_idx - (nfft / 2 + 1);
-        const int jm = jb < 0 ? jb + nfft : jb;
-        if (full) {
-            for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], tw_g[((unsigned)n * (unsigned)jm) % (unsigned)nfft]);
-        } else {
-            for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], twl[((unsigned)n * (unsigned)jm) % (unsigned)nfft]);
-        }
-    }
-    __syncthreads();
-    // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) ): unit phasors u[n] = x/|x| once
-    // per sample (into the dead B region), then u[n+1]*conj(u[n]) (the quotient of two unit phasors)
-    cplx* u = B;
-    for (int n = tid; n < nfft; n += BT_THREADS) {
-        const cplx p0 = xs[n];
-        const double m2 = p0.x * p0.x + p0.y * p0.y;
-        const double inv = rsqrt(m2);
-        u[n] = m2 > 0.0 ? make_double2(p0.x * inv, p0.y * inv) : make_double2(1.0, 0.0);   // angle(0) = 0
-    }
-    __syncthreads();
+    // :153-154  mean( exp(1i*angle(x(2:end))) ./ exp(1i*angle(x(1:end-1))) ): unit phasors u[n] = x/|x|, then
+    // u[n+1]*conj(u[n]) (the quotient of two unit phasors).  One pass: every lane derotates and normalises the two
+    // samples of its product itself (each u[n] is formed twice, identically) -- a rotated copy of the burst and a buffer
+    // of phasors cost two more passes over LDS and two barriers; xs stays as gathered (the gate below rotates on read).
+    const int jb = max_idx - (nfft / 2 + 1);
+    const unsigned jm = (unsigned)(jb < 0 ? jb + nfft : jb);
     double sr = 0.0, si = 0.0;
-    for (int n = tid; n < nfft - 1; n += BT_THREADS) {
-        const cplx ua = u[n + 1], ub = u[n];
-        sr += ua.x * ub.x + ua.y * ub.y;
-        si += ua.y * ub.x - ua.x * ub.y;
+    {
+        auto unit = [](const cplx& p0) {
+            const double m2 = p0.x * p0.x + p0.y * p0.y;
+            const double inv = rsqrt(m2);
+            return m2 > 0.0 ? make_double2(p0.x * inv, p0.y * inv) : make_double2(1.0, 0.0);   // angle(0) = 0
+        };
+        auto pass = [&](const cplx* tw) {
+            for (int n = tid; n < nfft - 1; n += BT_THREADS) {
+                const unsigned i0 = ((unsigned)n * jm) % (unsigned)nfft;
+                const unsigned i1 = i0 + jm >= (unsigned)nfft ? i0 + jm - (unsigned)nfft : i0 + jm;
+                const cplx ub = unit(cmul(xs[n], tw[i0]));
+                const cplx ua = unit(cmul(xs[n + 1], tw[i1]));
+                sr += ua.x * ub.x + ua.y * ub.y;
+                si += ua.y * ub.x - ua.x * ub.y;
+            }
+        };
+        if (full) pass(tw_g); else pass(twl);
     }
     sr = wave_sum(sr);
     si = wave_sum(si);
@@ -232,9 +371,14 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
         base[tid - 64] = make_double2(cs, -sn);
     }
     __syncthreads();
-    for (int n = tid; n < nfft; n += BT_THREADS) xs[n] = cmul(xs[n], cmul(base[n >> 4], pw[n & 15]));
-    __syncthreads();
-    fft37_step1_sym(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS);   // (the burst itself is not needed again)
+    // both rotations (:152's bin shift and this one) are applied as the 37-point step first reads each sample
+    if (full) {
+        fft37_step1_sym<true>(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS, [&](int n, const cplx& v) {
+            return cmul(cmul(v, tw_g[((unsigned)n * jm) % (unsigned)nfft]), cmul(base[n >> 4], pw[n & 15])); });
+    } else {
+        fft37_step1_sym<true>(xs, B, w37, tw_g, nfft, N2, ldb, tid, BT_THREADS, [&](int n, const cplx& v) {
+            return cmul(cmul(v, twl[((unsigned)n * jm) % (unsigned)nfft]), cmul(base[n >> 4], pw[n & 15])); });
+    }
     __syncthreads();
     const int hnl = (int)ceil(((double)nfft * 200e3 / sampling_rate) / 2.0);     // :22 half_noise_len
     const int nb = 2 * hnl;
@@ -993,7 +1137,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long lon
     if (tid == 0) { pk.p = -1.0; pk.tie = 0; pk.k = 0; res[0] = 0.0; res[1] = 0.0; }
     __syncthreads();
     // ---- stage 0: the fine search's exact last word per window -> FINE_DECIDE (FCCH_fine_correction.m:52-137) ----
-    fine_verify_body<PC_THREADS>(shv, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
+    fine_verify_body<PC_THREADS, 6>(shv, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
                                  a.cert, a.n_open, smem, &pk);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1);
@@ -1011,7 +1155,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long lon
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 3);
     // ---- stage 1: bursts of the resampled stream (:141-165, :185-196) -> CARRIER_DECIDE + SCH window setup ----
-    burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res);
+    burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 4);
     pcr_exchange(mine_x + 2 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
@@ -1046,7 +1190,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long lon
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 9);
     // ---- stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124) ----
-    burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res);
+    burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res, true);
     __syncthreads();
     pcr_exchange(mine_x + 6 * H, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
     if (w != 0) return;                                             // workgroup 0 finishes the stream

@@ -614,7 +614,9 @@ __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 // burst kernels do not have (scratch in the loop).
 // PAD = false: the input is staged without xs_pad's bank padding (gather_carve's compact_xs).
 // ------------------------------------------------------------------------------------------------
-template <int NTP, bool PAD = true>
+// UNR: trips of the four-tap loop the compiler may overlap (2: the next trip's LDS reads under this trip's FMAs, ~20 more
+// registers; 1 where the caller has none to spare).
+template <int NTP, bool PAD = true, int UNR = 2>
 __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const double* __restrict__ c_s, int i0, int ntp_rt,
                                          cplx* y0, cplx* y1, cplx* y2, cplx* y3) {
 #define XSP(p_) (PAD ? xs_pad(p_) : (p_))
@@ -630,7 +632,7 @@ __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const doub
     // fetched together.  Every accumulator still takes its taps in the same order (oldest first), so the sums are
     // bit-identical to a one-tap loop.
     int t = 0;
-#pragma unroll 2
+#pragma unroll UNR
     for (; t + 4 <= ntp; t += 4) {
         const cplx* nx = xq + XSP(i0 + t + 4);
         const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
@@ -831,10 +833,11 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         // direct form order).  Each lane produces 4 consecutive outputs from a sliding register window.
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * NT) {
             cplx y0, y1, y2, y3;
-            // (the run-time-count form: the two-trip form of fir4_lds<47> needs ~20 more registers than the 80 the fused
-            // per-burst kernels have -- scratch in the loop; k_fine_cert, at 108 registers, uses it)
-            if (compact) fir4_lds<0, false>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
-            else fir4_lds<0>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            // (the run-time-count form, one trip at a time: the two-trip forms need ~20 more registers than the 80 the fused
+            // per-burst kernels have -- scratch in the loop, and a kernel with ANY scratch starts its workgroups later;
+            // k_fine_cert, at 108 registers, uses fir4_lds<47>)
+            if (compact) fir4_lds<0, false, 1>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            else fir4_lds<0, true, 1>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             out0[i0] = y0;
             if (i0 + 1 < cnt0) out0[i0 + 1] = y1;
             if (i0 + 2 < cnt0) out0[i0 + 2] = y2;
