@@ -1192,6 +1192,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long lon
     // ---- stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124) ----
     burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res, true);
     __syncthreads();
+    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 10);
     pcr_exchange(mine_x + 6 * H, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
     if (w != 0) return;                                             // workgroup 0 finishes the stream
     if (tid < 64) {

@@ -14,9 +14,16 @@
 #ifdef GSMCAL_DEVTIMING
 __device__ unsigned long long* g_stamps = nullptr;   // [kernel id][DEV_STAMP_BLOCKS][16], 100 MHz wall clock
 #define DEV_STAMP_BLOCKS 1024
+// -DGSMCAL_DEVTIMING_LIGHT=<kernel id>: only stamps 0, 9 and 10 of that kernel are compiled in (when do its workgroups start
+// and reach their last stage?) -- the full set changes the register allocation of the kernel it measures.
+#ifdef GSMCAL_DEVTIMING_LIGHT
+#define DEV_STAMP_ON(kid, i) ((kid) == GSMCAL_DEVTIMING_LIGHT && ((i) == 0 || (i) == 9 || (i) == 10))
+#else
+#define DEV_STAMP_ON(kid, i) true
+#endif
 #define DEV_STAMP(kid, blk, i)                                                                          \
     do {                                                                                                \
-        if (g_stamps && threadIdx.x == 0 && (blk) < DEV_STAMP_BLOCKS)                                   \
+        if (DEV_STAMP_ON(kid, i) && g_stamps && threadIdx.x == 0 && (blk) < DEV_STAMP_BLOCKS)          \
             g_stamps[((size_t)(kid) * DEV_STAMP_BLOCKS + (blk)) * 16 + (i)] = wall_clock64();          \
     } while (0)
 #else

@@ -25,11 +25,18 @@ def main():
     ap.add_argument("--distinct", type=int, default=64)
     ap.add_argument("--workload", default="calib")
     ap.add_argument("--mode", default="table")
+    ap.add_argument("--light", type=int, default=-1,
+                    help="kernel id (state.h KID_*): compile in only that kernel's stamps 0, 9, 10 (leaves its register allocation alone)")
     args = ap.parse_args()
+    global DEV
+    flags = ["-DGSMCAL_DEVTIMING"]
+    if args.light >= 0:
+        DEV = DEV.replace("_dev.so", f"_dev_light{args.light}.so")
+        flags.append(f"-DGSMCAL_DEVTIMING_LIGHT={args.light}")
     src = os.path.join(PKG, "csrc", "gsmcal.hip")
     if not os.path.exists(DEV) or os.path.getmtime(DEV) < max(os.path.getmtime(os.path.join(PKG, "csrc", f)) for f in os.listdir(os.path.join(PKG, "csrc"))):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                        "-DGSMCAL_DEVTIMING", src, "-o", DEV, "-ldl"], check=True)
+                        *flags, src, "-o", DEV, "-ldl"], check=True)
     os.environ["GSMCAL_LIB"] = DEV
     os.environ["GSMCAL_GRAPH"] = "0"
     import numpy as np
