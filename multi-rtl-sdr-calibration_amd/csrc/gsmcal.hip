@@ -218,6 +218,13 @@ struct ProfScope {
     }
 };
 
+// LAUNCH_GEOM: `kern_ref` when the call has the reference geometry (8x oversampling, 47 taps, ...: instantiations with
+// compile-time loop bounds and divisors), `kern_any` otherwise
+#define LAUNCH_GEOM(is_ref, c, kern_ref, kern_any, grid, block, shmem, ...)       \
+    do {                                                                          \
+        if (is_ref) LAUNCH(c, kern_ref, grid, block, shmem, __VA_ARGS__);         \
+        else LAUNCH(c, kern_any, grid, block, shmem, __VA_ARGS__);                \
+    } while (0)
 #define LAUNCH(c, kern, grid, block, shmem, ...)                                  \
     do {                                                                          \
         ProfScope ps__(c, #kern);                                                 \
@@ -398,8 +405,12 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         const FineCert* certp = nullptr;
         if (cert_ok) {
             RET_IF(ensure(c, c->cur->cert, (size_t)S * H * sizeof(FineCert)));
-            LAUNCH(c, k_fine_cert, dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
-                   g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open, fg);
+            if (g.ov == 8 && (!fg.raw || fg.ntaps == 47))
+                LAUNCH(c, (k_fine_cert<8, 47>), dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+                       g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open, fg);
+            else
+                LAUNCH(c, (k_fine_cert<0, 0>), dim3(H, S), dim3(fc_thr), clds, (const StreamState*)st, (const cplx*)win, sstride, wstride,
+                       g.fine_nshift, g.nfft, (const cplx*)c->tw.p, (FineCert*)c->cur->cert.p, H, open_items, n_open, fg);
             certp = (const FineCert*)c->cur->cert.p;
         } else {
             LAUNCH(c, k_fine_openall, dim3(H, S), dim3(64), 0, (const StreamState*)st, nchunk, H, open_items, n_open);
@@ -465,7 +476,10 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.win = win; pa.win_stream_stride = sstride; pa.win_stride = wstride;
                 pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
                 pa.with_totals = chain->table ? 1 : 0;
-                if (repl) LAUNCH(c, k_post_chain_r, dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
+                const bool ref_geom = g.ov == 8 && g.nfft == 148 * 8 && g.fine_nshift == 128 * 8 + 1 && g.sch_nshift == 11 * 8 + 1 &&
+                                      len_ts == 512 && wl_sch == 11 * 8 + 512 && src.ntaps == 47;
+                if (repl && ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
+                else if (repl) LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
                 else LAUNCH(c, k_post_chain, dim3(H, S), dim3(PC_THREADS), lds, st, pa);
                 CHECK_LAUNCH(c);
                 return 0;
@@ -493,7 +507,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         TailArgs tl;   // FCCH_fine_correction's carrier decision (+ the SCH stage's window setup) rides on the last burst
         RET_IF(make_tail(c, S, sa, next_sch_lvl >= 0 ? (STEP_CARRIER_DECIDE | STEP_SCH_SETUP) : STEP_CARRIER_DECIDE, lvl,
                          next_sch_lvl >= 0 ? next_sch_lvl : 0, tl));
-        LAUNCH(c, k_burst_tone<1>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
+        LAUNCH_GEOM(g.ov == 8 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_burst_tone<1, 8, 47>), (k_burst_tone<1, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
                g.nfft, (const cplx*)c->tw.p, g.ov, 1, tl);
     }
     CHECK_LAUNCH(c);
@@ -516,7 +530,7 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
         TailArgs tl;   // SCH_corr_rate_correction's decisions (+ the post stage's window setup) ride on the last window
         RET_IF(make_tail(c, S, sa, next_post_lvl >= 0 ? (STEP_SCH_DECIDE | STEP_POST_SETUP) : STEP_SCH_DECIDE, lvl,
                          next_post_lvl >= 0 ? next_post_lvl : 0, tl));
-        LAUNCH(c, k_window_sch, dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
+        LAUNCH_GEOM(g.ov == 8 && len_ts == 512 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_window_sch<8, 512, 47>), (k_window_sch<0, 0, 0>), dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
                len_ts, g.sch_nshift, tl);
     }
     CHECK_LAUNCH(c);
@@ -544,7 +558,7 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         }
         TailArgs tl;   // carrier_correct_post_SCH's decision (+ the calibration table row) rides on the last burst
         RET_IF(make_tail(c, S, sa, table ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, lvl, 0, tl));
-        LAUNCH(c, k_burst_tone<0>, dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
+        LAUNCH_GEOM(g.ov == 8 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_burst_tone<0, 8, 47>), (k_burst_tone<0, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
                g.nfft, (const cplx*)c->tw.p, g.ov, 0, tl);
     }
     CHECK_LAUNCH(c);
@@ -928,7 +942,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fir_decim_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_fine_cert, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fine_cert<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_fine_cert<8, 47>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fine_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_front_fast47_sym, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -938,15 +953,19 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_thr, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_burst_tone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_burst_tone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_window_sch, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_window_sch<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_post_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_post_chain_r, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_post_chain_r<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_post_chain_r<8, 512, 47>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_equalise, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sch_fd_training, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_fft_burst<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<0, 8, 47>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_burst_tone<1, 8, 47>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_window_sch<8, 512, 47>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipGetLastError();   // an attribute request the device rejects must not surface at the first launch
     gsmcal_ctx* c = new gsmcal_ctx();
     gsmcal_params_default(&c->params);
@@ -1610,7 +1629,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             ta.dst = (cplx*)d_r_correct + (size_t)lo * n; ta.dst_stream_stride = n;
             const size_t tlds = stream_tile_lds(ntaps);
             if (tlds <= 64 * 1024) {
-                LAUNCH(c, k_stream_tile, dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
+                LAUNCH_GEOM(ta.ntaps == 47, c, (k_stream_tile<47>), (k_stream_tile<0>), dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
                 CHECK_LAUNCH(c);
             } else {                                        // very long filters: the general tile gather
                 const int tiles = (int)((n + TILE - 1) / TILE);

@@ -939,20 +939,28 @@ __device__ __forceinline__ void stream_tail(StreamState* __restrict__ sts, const
     step_body<true>(sts, t.sa, t.steps, t.lvl_a, t.lvl_b, blockIdx.y, (StreamState*)smem, kid);
 }
 
-template <int GATE>
+// OV, LT, NTAPS > 0 (here and in the kernels below): the reference geometry as compile-time constants, see k_post_chain_r
+template <int GATE, int OV, int NTAPS>
 __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_burst_tone(StreamState* __restrict__ sts, GatherArgs a, int nfft, const cplx* __restrict__ tw_g, int ov, int prior_mode,
+k_burst_tone(StreamState* __restrict__ sts, GatherArgs a_in, int nfft_rt, const cplx* __restrict__ tw_g, int ov_rt, int prior_mode,
              TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GatherArgs a = a_in;
+    const int nfft = OV > 0 ? 148 * OV : nfft_rt, ov = OV > 0 ? OV : ov_rt;
+    if (OV > 0) { a.len = 148 * OV; a.ntaps = NTAPS; }
     burst_tone_body<GATE>(sts, a, nfft, tw_g, ov, prior_mode, smem);
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 5);
     stream_tail(sts, tail, smem, GATE ? KID_BT1 : KID_BT0);
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 6);
 }
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) k_window_sch(StreamState* __restrict__ sts, GatherArgs a,
-                                                    const cplx* __restrict__ ts, int len_ts, int nshift, TailArgs tail) {
+template <int OV, int LT, int NTAPS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) k_window_sch(StreamState* __restrict__ sts, GatherArgs a_in,
+                                                    const cplx* __restrict__ ts, int len_ts_rt, int nshift_rt, TailArgs tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GatherArgs a = a_in;
+    const int len_ts = OV > 0 ? LT : len_ts_rt, nshift = OV > 0 ? 11 * OV + 1 : nshift_rt;
+    if (OV > 0) { a.len = 11 * OV + LT; a.ntaps = NTAPS; }
     window_sch_body(sts, a, ts, len_ts, nshift, smem);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 3);
     stream_tail(sts, tail, smem, KID_SCH);
@@ -1114,8 +1122,22 @@ __device__ __forceinline__ void pcr_exchange(unsigned long long* __restrict__ sl
     __syncthreads();
 }
 
+// OV > 0: the oversampling ratio, the training-sequence length LT and the tap count NTAPS as compile-time constants (the
+// reference geometry: 8, 512, 47 -- burst length 148*OV, 128*OV+1 fine shifts, 11*OV+1 SCH shifts): every `% nfft`, `/ N2`
+// and loop bound of the stage bodies folds, 3.4 us of the launch at 64 streams.  OV = 0: all taken from the arguments.
+template <int OV, int LT, int NTAPS>
 __global__ void __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a, unsigned long long* __restrict__ xch, unsigned* __restrict__ epoch) {
+k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long long* __restrict__ xch, unsigned* __restrict__ epoch) {
+    PostChainArgs a = a_in;
+    if (OV > 0) {
+        a.ov = OV; a.sa.ov = OV;
+        a.nfft = 148 * OV; a.ga1.len = 148 * OV; a.ga0.len = 148 * OV;
+        a.fine_nshift = 128 * OV + 1;
+        a.sch_nshift = 11 * OV + 1;
+        a.len_ts = LT; a.sa.len_ts = LT;
+        a.ga_sch.len = 11 * OV + LT;
+        a.ga1.ntaps = NTAPS; a.ga_sch.ntaps = NTAPS; a.ga0.ntaps = NTAPS;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     __shared__ unsigned long long all[64];
     __shared__ double res[2];

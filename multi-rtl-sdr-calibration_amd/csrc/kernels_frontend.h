@@ -955,6 +955,8 @@ __device__ __forceinline__ StRange st_range(long tile, long nq, long n0, long n2
     return r;
 }
 
+// NTAPS > 0: the tap count as a compile-time constant (47, the drivers' fir1(46)); 0: from the arguments
+template <int NTAPS>
 __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* __restrict__ sts, StreamTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.y, tid = threadIdx.x;
@@ -974,7 +976,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
     if (tile >= ntile) return;
     const long tile_end = tile + ST_TPB < ntile ? tile + ST_TPB : ntile;
     // ---- LDS carve ----
-    const int ntp = a.ntaps;
+    const int ntp = NTAPS > 0 ? NTAPS : a.ntaps;
     const size_t span_max = 1024 + 8 + ntp + 24;
     const size_t xs_n = span_max + span_max / 4 + 16, bufn = 1024 + 16;
     cplx* buf0 = (cplx*)smem;                                   // level 0 (FIR output)
