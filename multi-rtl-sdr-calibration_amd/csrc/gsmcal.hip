@@ -507,7 +507,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         TailArgs tl;   // FCCH_fine_correction's carrier decision (+ the SCH stage's window setup) rides on the last burst
         RET_IF(make_tail(c, S, sa, next_sch_lvl >= 0 ? (STEP_CARRIER_DECIDE | STEP_SCH_SETUP) : STEP_CARRIER_DECIDE, lvl,
                          next_sch_lvl >= 0 ? next_sch_lvl : 0, tl));
-        LAUNCH_GEOM(g.ov == 8 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_burst_tone<1, 8, 47>), (k_burst_tone<1, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
+        LAUNCH_GEOM(g.ov == 8 && src.kind == SRC_RAW && src.ntaps == 47 && lvl == 0, c, (k_burst_tone<1, 8, 47>), (k_burst_tone<1, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl + 1, g.nfft, burst_scratch(g)), st, ga,
                g.nfft, (const cplx*)c->tw.p, g.ov, 1, tl);
     }
     CHECK_LAUNCH(c);
@@ -530,7 +530,7 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
         TailArgs tl;   // SCH_corr_rate_correction's decisions (+ the post stage's window setup) ride on the last window
         RET_IF(make_tail(c, S, sa, next_post_lvl >= 0 ? (STEP_SCH_DECIDE | STEP_POST_SETUP) : STEP_SCH_DECIDE, lvl,
                          next_post_lvl >= 0 ? next_post_lvl : 0, tl));
-        LAUNCH_GEOM(g.ov == 8 && len_ts == 512 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_window_sch<8, 512, 47>), (k_window_sch<0, 0, 0>), dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
+        LAUNCH_GEOM(g.ov == 8 && len_ts == 512 && src.kind == SRC_RAW && src.ntaps == 47 && lvl == 2, c, (k_window_sch<8, 512, 47>), (k_window_sch<0, 0, 0>), dim3(H, S), dim3(512), fused_lds(src, lvl, wl, scratch), st, ga, (const cplx*)c->ts.p,
                len_ts, g.sch_nshift, tl);
     }
     CHECK_LAUNCH(c);
@@ -558,7 +558,7 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
         }
         TailArgs tl;   // carrier_correct_post_SCH's decision (+ the calibration table row) rides on the last burst
         RET_IF(make_tail(c, S, sa, table ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, lvl, 0, tl));
-        LAUNCH_GEOM(g.ov == 8 && (src.kind != SRC_RAW || src.ntaps == 47), c, (k_burst_tone<0, 8, 47>), (k_burst_tone<0, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
+        LAUNCH_GEOM(g.ov == 8 && src.kind == SRC_RAW && src.ntaps == 47 && lvl == 3, c, (k_burst_tone<0, 8, 47>), (k_burst_tone<0, 0, 0>), dim3(H, S), dim3(BT_THREADS), fused_lds(src, lvl, g.nfft, burst_scratch(g)), st, ga,
                g.nfft, (const cplx*)c->tw.p, g.ov, 0, tl);
     }
     CHECK_LAUNCH(c);

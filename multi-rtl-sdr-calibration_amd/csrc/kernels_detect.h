@@ -1608,9 +1608,8 @@ __device__ __forceinline__ float fc_group8_sum(float v) {     // sum over the 8 
 __host__ __device__ inline int fc_gcd64(int n) { int b = 64; while (n % b) b >>= 1; return b; }
 // threads of k_fine_cert: 8 per chunk, at least 256.  (320 would save the nearly empty third round of the level-1 phase --
 // 69 blocks handed out 32 at a time -- but five-wave workgroups no longer sit three to a CU: measured 77 us against 59.)
-__host__ inline int fc_threads(int nshift) {
-    const int n = ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64;
-    return n < 256 ? 256 : n;
+__host__ __device__ constexpr int fc_threads(int nshift) {
+    return ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64 < 256 ? 256 : ((nshift - 1) / FS_CHUNK * FC_NB + 63) / 64 * 64;
 }
 // One element of padding after every 128: lane groups that work 64 shifts apart (the chunks of the slide phase) would
 // otherwise all hit the same LDS banks (8-way; the SQ counters showed 4 bank-conflict cycles per LDS instruction in this
@@ -1651,7 +1650,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     if (OV > 0) fg.ntaps = NTAPS;
     const int nstep = nshift - 1, wlen = nstep + nfft;
     const int B = fc_gcd64(nfft), nA = nfft / B, nM = wlen / B, nchunk = nstep / FS_CHUNK;
-    const int nthr = blockDim.x;                          // >= 8 * nchunk, whole waves
+    const int nthr = blockDim.x;                          // >= 8 * nchunk, whole waves (as a compile-time constant: 1.2 us SLOWER)
     cplx* xs = (cplx*)smem;                               // window
     const size_t r1 = (size_t)FC_NB * nM * sizeof(cplx), e1 = (size_t)(nstep + 2) * sizeof(double);
     cplx* Sp = xs + FC_XP(wlen);                          // S partials [j][m]

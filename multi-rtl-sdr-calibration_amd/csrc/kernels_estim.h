@@ -947,7 +947,7 @@ k_burst_tone(StreamState* __restrict__ sts, GatherArgs a_in, int nfft_rt, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GatherArgs a = a_in;
     const int nfft = OV > 0 ? 148 * OV : nfft_rt, ov = OV > 0 ? OV : ov_rt;
-    if (OV > 0) { a.len = 148 * OV; a.ntaps = NTAPS; }
+    if (OV > 0) { a.len = 148 * OV; a.ntaps = NTAPS; a.src_kind = SRC_RAW; a.tiles = 0; a.level = GATE ? 1 : 3; }   // (the chain on raw bytes from level 0: bursts at levels 1 and 3)
     burst_tone_body<GATE>(sts, a, nfft, tw_g, ov, prior_mode, smem);
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 5);
     stream_tail(sts, tail, smem, GATE ? KID_BT1 : KID_BT0);
@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GatherArgs a = a_in;
     const int len_ts = OV > 0 ? LT : len_ts_rt, nshift = OV > 0 ? 11 * OV + 1 : nshift_rt;
-    if (OV > 0) { a.len = 11 * OV + LT; a.ntaps = NTAPS; }
+    if (OV > 0) { a.len = 11 * OV + LT; a.ntaps = NTAPS; a.src_kind = SRC_RAW; a.tiles = 0; a.level = 2; }
     window_sch_body(sts, a, ts, len_ts, nshift, smem);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 3);
     stream_tail(sts, tail, smem, KID_SCH);
@@ -1129,6 +1129,12 @@ template <int OV, int LT, int NTAPS>
 __global__ void __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long long* __restrict__ xch, unsigned* __restrict__ epoch) {
     PostChainArgs a = a_in;
+    // what the host guarantees for this kernel (run_fine: raw source, chain starting at level 0), as constants for the gathers
+    a.ga1.src_kind = SRC_RAW; a.ga_sch.src_kind = SRC_RAW; a.ga0.src_kind = SRC_RAW;
+    a.ga1.tiles = 0; a.ga_sch.tiles = 0; a.ga0.tiles = 0;
+    a.ga1.level = 1; a.ga_sch.level = 2; a.ga0.level = 3;
+    a.ga1.pad = 1; a.ga_sch.pad = 0; a.ga0.pad = 1;
+    a.lvl_fine = 0; a.lvl_sch = 2; a.lvl_post = 3;
     if (OV > 0) {
         a.ov = OV; a.sa.ov = OV;
         a.nfft = 148 * OV; a.ga1.len = 148 * OV; a.ga0.len = 148 * OV;
