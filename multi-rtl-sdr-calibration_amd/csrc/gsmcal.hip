@@ -698,6 +698,7 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     const int fft_len = 1 << (int)floor(log2(148.0 / (double)dec_ratio));
     const long n_first = (long)ceil(23.0 * 1250.0 / (double)dec_ratio);
     const long nwin = n_first - (fft_len - 1);
+    a.g_fft_len = fft_len; a.g_n_first = n_first;
     const size_t lds = coarse_scan_lds(n_first, 10 * fft_len);
     if (lds > 159 * 1024 || nwin < 1) return GSMCAL_E_UNSUPPORTED;
     // latency path (few streams: one wave of k_coarse_snr workgroups still fits the chip): k_coarse_snr fills in every window of

@@ -186,6 +186,7 @@ struct CoarseArgs {
     double th0; int min_hits;                 // mode 0: gsmcal_params.coarse_th_db (FCCH_coarse_position.m:21), min_hits for the fine setup
     const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
     int npartial; long n0;                    //            and the capture length they divide by
+    int g_fft_len; long g_n_first;            // mode 0: FCCH_coarse_position.m:15-25 worked out by the host (0: derive them here)
 };
 
 // raw2iq.m:8 from the front kernel's per-block partial sums: exact integer totals, one fp64 divide each
@@ -222,14 +223,16 @@ __device__ __forceinline__ DecView dec_view(const CoarseArgs& a, int stream, dou
 
 struct CoarseGeom { int fft_len, mv_len; double th; long n_first, nwin; };
 
+template <bool HOST_VALUES = true>
 __device__ __forceinline__ CoarseGeom coarse_geom(const CoarseArgs& a) {
     CoarseGeom g;
     if (a.mode == 0) {
         // FCCH_coarse_position.m:15-25
-        g.fft_len = 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
+        // (the host's values when it sent them: a log2, a ceil and two divides per thread are a tenth of k_coarse_snr's instructions)
+        g.fft_len = HOST_VALUES && a.g_fft_len > 0 ? a.g_fft_len : 1 << (int)floor(log2(148.0 / (double)a.decimation_ratio));
         g.th = a.th0;
         g.mv_len = 10 * g.fft_len;
-        g.n_first = (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
+        g.n_first = HOST_VALUES && a.g_fft_len > 0 ? a.g_n_first : (long)ceil(23.0 * 1250.0 / (double)a.decimation_ratio);
     } else {
         g.fft_len = a.fft_len; g.mv_len = a.mv_len; g.th = a.th; g.n_first = a.len;
     }
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     double* snr_s = hop_sig_base + 2 * MAXH;
     StreamState* st_g = sts + blockIdx.x;
     const long len = a.len;
-    const CoarseGeom g = coarse_geom(a);
+    const CoarseGeom g = coarse_geom<false>(a);   // (derived here, under the latency of the loads below: with the host's values this kernel ran 1.2 us SLOWER)
     const int fft_len = g.fft_len, mv_len = g.mv_len;
     const double th = g.th;
     const int tid = threadIdx.x;
