@@ -2058,6 +2058,35 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
         }
         fprintf(stderr, "\n");
     }
+    // what the certificate of the last batch left open, and what the chunk sweep handed on
+    Lane& L = c->lanes[0];
+    if (L.cert.p && L.chunkrec.p && L.state.p && c->last_S > 0 && L.win_l0_H > 0) {
+        const int S = c->last_S, H = L.win_l0_H;
+        std::vector<FineCert> fc((size_t)S * H);
+        std::vector<StreamState> st(S);
+        HIPCHK(c, hipMemcpy(fc.data(), L.cert.p, fc.size() * sizeof(FineCert), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(st.data(), L.state.p, st.size() * sizeof(StreamState), hipMemcpyDeviceToHost));
+        const Geom g(8);
+        const int nchunk = (g.fine_nshift - 1 + FS_CHUNK - 1) / FS_CHUNK;
+        std::vector<ChunkRec> rec((size_t)S * H * nchunk);
+        if (L.chunkrec.cap >= rec.size() * sizeof(ChunkRec)) {
+            HIPCHK(c, hipMemcpy(rec.data(), L.chunkrec.p, rec.size() * sizeof(ChunkRec), hipMemcpyDeviceToHost));
+            int hist[20] = {0}, nwin = 0, cand_hist[8] = {0}, win_with_cand = 0;
+            for (int s = 0; s < S; ++s)
+                for (int w = 0; w < H && w < st[s].n_fine_ws; ++w) {
+                    const FineCert& f = fc[(size_t)s * H + w];
+                    ++nwin; ++hist[f.nch < 19 ? f.nch : 19];
+                    int tot = 0;
+                    for (int k = 0; k < f.nch; ++k) { const int cnt = rec[((size_t)s * H + w) * nchunk + k].count; tot += cnt < 0 ? 100 : cnt; }
+                    if (f.nch > 0) { ++cand_hist[tot < 7 ? tot : 7]; if (tot) ++win_with_cand; }
+                }
+            fprintf(stderr, "certificate: %d windows; open chunks per window:", nwin);
+            for (int i = 0; i < 20; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+            fprintf(stderr, "\n  candidates the chunk sweep handed to the exact pass, per window with open chunks:");
+            for (int i = 0; i < 8; ++i) if (cand_hist[i]) fprintf(stderr, " %d%s:%d", i, i == 7 ? "+" : "", cand_hist[i]);
+            fprintf(stderr, "  (%d windows with any)\n", win_with_cand);
+        }
+    }
     return 0;
 }
 #endif
