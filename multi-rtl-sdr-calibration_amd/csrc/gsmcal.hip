@@ -610,6 +610,7 @@ static const auto k_front_fast31 = &k_front_fast<31, false>;
 static const auto k_coarse_scan_lat = &k_coarse_scan<3, true>;   // (one register budget serves both: no spills at 165 registers)
 static const auto k_coarse_scan_thr = &k_coarse_scan<3, true>;
 static const auto k_coarse_scan_gen = &k_coarse_scan<2, false>;
+static const auto k_coarse_scan_ref = &k_coarse_scan<3, true, true>;   // the drivers' window geometry as constants
 
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                 cplx* d_out, long out_stride) {
@@ -718,11 +719,13 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = ntab;
     c->cur->snr_stride = ntab; c->cur->snr_nmove = nwin;
     const dim3 sgrid(sblocks, S);
-    if (fft_len == 16 && a.snr_nwin > 0) LAUNCH(c, (k_coarse_snr<true, true>), sgrid, dim3(CS_SNR_THREADS), 0, a);
-    else if (fft_len == 16) LAUNCH(c, k_coarse_snr<true>, sgrid, dim3(256), 0, a);
+    const bool refg = dec_ratio == 8 && fft_len == 16 && n_first == 3594;
+    if (fft_len == 16 && a.snr_nwin > 0) LAUNCH_GEOM(refg, c, (k_coarse_snr<true, true, true>), (k_coarse_snr<true, true>), sgrid, dim3(CS_SNR_THREADS), 0, a);
+    else if (fft_len == 16) LAUNCH_GEOM(refg, c, (k_coarse_snr<true, false, true>), (k_coarse_snr<true>), sgrid, dim3(256), 0, a);
     else LAUNCH(c, k_coarse_snr<false>, sgrid, dim3(256), 0, a);
     // register budgets of the same kernel: small batches run one workgroup per CU anyway, big ones want four
     if (fft_len != 16) LAUNCH(c, k_coarse_scan_gen, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+    else if (refg) LAUNCH(c, k_coarse_scan_ref, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     else if (S <= 512) LAUNCH(c, k_coarse_scan_lat, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     else LAUNCH(c, k_coarse_scan_thr, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
     CHECK_LAUNCH(c);
@@ -954,6 +957,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_thr, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan_ref, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_window_sch<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);

@@ -314,10 +314,12 @@ __device__ __forceinline__ unsigned screen4(const cplx* xt, int b, double cr, do
 //   increasing in rho.  A window with |r1| < g(rho_X) r0 therefore has SNR < X dB = a.snr_screen_db: it gets -inf ("below X")
 //   and no FFT.  The hop walk only asks "snr - hit_avg_snr > th" and uses the table only when hit_avg_snr + th > X.
 // The survivors are compacted and computed in full after the moving search's windows.
-template <bool FFT16, bool SCREEN = false>
+// REFG: FCCH_coarse_position on a stream decimated to an eighth of the symbol rate (the drivers' geometry: 16-point windows,
+// 160-window average, 3594 samples of moving search) -- the window geometry as compile-time constants
+template <bool FFT16, bool SCREEN = false, bool REFG = false>
 __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_coarse_snr(CoarseArgs a) {
     __shared__ cplx tw[64];
-    const CoarseGeom g = coarse_geom(a);
+    const CoarseGeom g = REFG ? CoarseGeom{16, 160, a.th0, 3594L, 3594L - 15L} : coarse_geom(a);
     if (g.fft_len > 64 || g.fft_len < 2 || g.n_first > a.len) return;   // the scan kernel reports the index error
     const int tid = threadIdx.x;
     if (!FFT16) coarse_twiddles(tw, g.fft_len, tid, 256);
@@ -428,8 +430,10 @@ __host__ __device__ inline size_t coarse_scan_lds_fixed() {
     return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + 4 * CS_ROW * sizeof(cplx) + (2 * 11 * 17 + 2 * MAXH) * sizeof(double);
 }
 
-template <int WAVES, bool FFT16>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a) {
+template <int WAVES, bool FFT16, bool REFG = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a_in) {
+    CoarseArgs a = a_in;
+    if (REFG) { a.mode = 0; a.decimation_ratio = 8; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sh_hit;     // first hit window (0-based) or INT_MAX
     __shared__ double sh_avg;  // sum/mv_len seen by the hit window
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     double* snr_s = hop_sig_base + 2 * MAXH;
     StreamState* st_g = sts + blockIdx.x;
     const long len = a.len;
-    const CoarseGeom g = coarse_geom<false>(a);   // (derived here, under the latency of the loads below: with the host's values this kernel ran 1.2 us SLOWER)
+    const CoarseGeom g = REFG ? CoarseGeom{16, 160, a.th0, 3594L, 3594L - 15L} : coarse_geom<false>(a);   // (derived here, under the latency of the loads below: with the host's values this kernel ran 1.2 us SLOWER)
     const int fft_len = g.fft_len, mv_len = g.mv_len;
     const double th = g.th;
     const int tid = threadIdx.x;
