@@ -48,7 +48,7 @@ struct ProfRec {
 // A lane = one HIP stream + the per-stream-group scratch of the chain.  A batch is split over several
 // lanes so that one group's latency-bound stages (coarse scan, decisions, small FFTs) run underneath
 // another group's compute-bound fine search.  Lane 0 runs on the context's own stream.
-#define MAX_LANES 16
+#define MAX_LANES 32
 struct Lane {
     hipStream_t stream = nullptr;
     DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr, xch;
@@ -92,6 +92,7 @@ struct gsmcal_ctx {
     bool graph_always = false;      // GSMCAL_GRAPH=2: also single-stream plans (default: only plans that fork onto internal streams)
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
+    int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
     bool reuse_l0 = true;           // GSMCAL_REUSE_L0=0: every per-burst gather filters its raw bytes again
@@ -711,6 +712,11 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
         ntab = len - (fft_len - 1);
         a.snr_nwin = ntab;
         a.snr_screen_db = c->snr_screen_db;
+        {
+            const double rho = pow(10.0, a.snr_screen_db / 10.0);
+            const double gx = (0.9238795325112867 * rho - 1.0) / (rho + 1.0);
+            a.snr_gx2 = gx > 0.0 ? gx * gx * (1.0 - 1e-9) : 0.0;   // (margin over the ~1e-14 rounding of the sums)
+        }
         const long rest = ntab - nwin;
         if ((rest + sblocks - 1) / sblocks > CS_TILE - 3) sblocks = (unsigned)((rest + CS_TILE - 4) / (CS_TILE - 3));
         a.snr_tile = (int)((((rest + sblocks - 1) / sblocks) + 3) & ~3L);
@@ -777,7 +783,7 @@ int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
     // kernels in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms for 12,800 captures), so big scanner
     // batches are cut into pipeline stages instead: the front kernels run one after the other (chained by events) and
     // each stage's detector runs underneath the next stage's front kernel.
-    int nl = latency_bound ? c->n_lanes_cfg : (d >= 8192 ? 16 : (d >= 2048 ? 8 : 1));
+    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 8192 ? 16 : (d >= 2048 ? 8 : 1)));
     if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;
@@ -982,6 +988,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
+    const char* sst = getenv("GSMCAL_SCAN_STAGES");
+    if (sst && atoi(sst) >= 1) c->scan_stages = atoi(sst);
     const char* lm = getenv("GSMCAL_LANE_MIN");
     if (lm && atoi(lm) >= 1) c->lane_min = atoi(lm);
     const char* ce = getenv("GSMCAL_CERT");

@@ -186,6 +186,7 @@ struct CoarseArgs {
     double th0; int min_hits;                 // mode 0: gsmcal_params.coarse_th_db (FCCH_coarse_position.m:21), min_hits for the fine setup
     const unsigned long long* partial;        // mean_corr: per-block byte sums of k_front_fused, [S][npartial][2]
     int npartial; long n0;                    //            and the capture length they divide by
+    double snr_gx2;                           // the screening level of k_coarse_snr as g(rho_X)^2 (see there)
     int g_fft_len; long g_n_first;            // mode 0: FCCH_coarse_position.m:15-25 worked out by the host (0: derive them here)
 };
 
@@ -325,35 +326,63 @@ __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((
     if (!FFT16) coarse_twiddles(tw, g.fft_len, tid, 256);
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + tid;
-    double mr = 0.0, mi = 0.0;
-    if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }   // (whole block: wave 0 adds, barrier)
-    const DecView s = dec_view(a, blockIdx.y, mr, mi);
-    DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    double* tab = a.snr_g + (size_t)blockIdx.y * a.snr_stride;
+    // the stream's mean comes from the front kernel's partial byte sums: requested by the first wave BEFORE the samples below, so
+    // that the two round trips to L2 overlap (a tenth of this kernel's time); summed after them
+    unsigned long long pvi[4] = {0, 0, 0, 0}, pvq[4] = {0, 0, 0, 0};
+    const bool pre_mean = FFT16 && a.mean_corr && a.npartial <= 256;
+    if (pre_mean && tid < 64) {
+        const unsigned long long* pp = a.partial + (size_t)blockIdx.y * a.npartial * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = tid + 64 * k;
+            if (b < a.npartial) { pvi[k] = pp[2 * b]; pvq[k] = pp[2 * b + 1]; }
+        }
+    }
+    __shared__ cplx xw[FFT16 ? 256 + 16 : 1];
+    __shared__ cplx xt[SCREEN ? CS_TILE + 20 : 1];
+    __shared__ unsigned short list[SCREEN ? CS_TILE : 1];
+    __shared__ int sh_cnt;
+    const int nthr = SCREEN ? CS_SNR_THREADS : 256;
+    int nw = 0;
+    long w0 = 0;
     if (FFT16) {
         // the block's 256 windows overlap in all but one sample each: stage the 271 samples they cover in LDS once
-        // instead of 16 loads per window through the vector cache
-        __shared__ cplx xw[256 + 16];
-        __shared__ cplx xt[SCREEN ? CS_TILE + 20 : 1];
-        __shared__ unsigned short list[SCREEN ? CS_TILE : 1];
-        __shared__ int sh_cnt;
-        const int nthr = SCREEN ? CS_SNR_THREADS : 256;
+        // instead of 16 loads per window through the vector cache (raw: the DC term is removed in the spectrum)
+        const cplx* sp = a.s + (size_t)blockIdx.y * a.s_stride;
         const long b0 = (long)blockIdx.x * 256;
-        for (int j = tid; j < 256 + 15; j += nthr) xw[j] = b0 + j < a.len ? s.s[b0 + j] : make_double2(0.0, 0.0);
-        int nw = 0;
-        long w0 = 0;
+        for (int j = tid; j < 256 + 15; j += nthr) xw[j] = b0 + j < a.len ? sp[b0 + j] : make_double2(0.0, 0.0);
         if (SCREEN) {
             w0 = g.nwin + (long)blockIdx.x * a.snr_tile;
             const long left = a.snr_nwin - w0;
             nw = left <= 0 ? 0 : (left < a.snr_tile ? (int)left : a.snr_tile);
-            for (int j = tid; j < nw + 15; j += nthr) xt[j] = s.s[w0 + j];
+            for (int j = tid; j < nw + 15; j += nthr) xt[j] = sp[w0 + j];
             if (tid == 0) sh_cnt = 0;
         }
+    }
+    double mr = 0.0, mi = 0.0;
+    if (pre_mean) {
+        __shared__ unsigned long long sh_tot2[2];
+        if (tid < 64) {
+            unsigned long long si = (pvi[0] + pvi[1]) + (pvi[2] + pvi[3]), sq = (pvq[0] + pvq[1]) + (pvq[2] + pvq[3]);   // (integers: any order)
+            for (int off = 32; off > 0; off >>= 1) {
+                si += __shfl_down(si, off, 64);
+                sq += __shfl_down(sq, off, 64);
+            }
+            if (tid == 0) { sh_tot2[0] = si; sh_tot2[1] = sq; }
+        }
+        __syncthreads();                                 // (also: xw / xt complete)
+        mr = (double)sh_tot2[0] / (double)a.n0;          // raw2iq.m:8, as in stream_mean
+        mi = (double)sh_tot2[1] / (double)a.n0;
+    } else {
+        if (a.mean_corr) { unsigned long long ti, tq; stream_mean(a, blockIdx.y, &mr, &mi, &ti, &tq); }   // (whole block: wave 0 adds, barrier)
         __syncthreads();
+    }
+    const DecView s = dec_view(a, blockIdx.y, mr, mi);
+    DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    double* tab = a.snr_g + (size_t)blockIdx.y * a.snr_stride;
+    if (FFT16) {
         if (SCREEN && nw > 0) {
-            const double rho = exp10(a.snr_screen_db / 10.0);
-            const double gx = (0.9238795325112867 * rho - 1.0) / (rho + 1.0);
-            const double gx2 = gx > 0.0 ? gx * gx * (1.0 - 1e-9) : 0.0;   // (margin over the ~1e-14 rounding of the sums)
+            const double gx2 = a.snr_gx2;                // g(rho_X)^2 with its margin, from the host (an exp10 and a divide per thread otherwise)
             for (int b = 4 * tid; b < nw; b += 4 * nthr) {
                 const unsigned need = screen4(xt, b, s.cr, s.ci, gx2);
 #pragma unroll
