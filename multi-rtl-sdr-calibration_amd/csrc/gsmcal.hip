@@ -2016,6 +2016,17 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
     HIPCHK(c, hipMemcpy(h.data(), g_stamp_buf, h.size() * 8, hipMemcpyDeviceToHost));
     void* z = nullptr;
     HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &z, sizeof(z)));
+    if (const char* dump = getenv("GSMCAL_DEVTIMING_DUMP")) {          // raw stamps: kernel id, block, stamp, 10 ns ticks
+        if (FILE* f = fopen(dump, "w")) {
+            for (int k = 0; k < KID_N; ++k)
+                for (int b = 0; b < DEV_STAMP_BLOCKS; ++b)
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned long long t = h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16 + i];
+                        if (t) fprintf(f, "%d,%d,%d,%llu\n", k, b, i, t);
+                    }
+            fclose(f);
+        }
+    }
     for (int k = 0; k < KID_N; ++k) {
         unsigned long long t0 = ~0ull, t1 = 0;
         double ph[15] = {0}; int pc[15] = {0}; int nb = 0;

@@ -14,10 +14,13 @@
 #ifdef GSMCAL_DEVTIMING
 __device__ unsigned long long* g_stamps = nullptr;   // [kernel id][DEV_STAMP_BLOCKS][16], 100 MHz wall clock
 #define DEV_STAMP_BLOCKS 1024
-// -DGSMCAL_DEVTIMING_LIGHT=<kernel id>: only stamps 0, 9 and 10 of that kernel are compiled in (when do its workgroups start
+// -DGSMCAL_DEVTIMING_LIGHT=<kernel id>: only the stamps of that kernel in GSMCAL_DEVTIMING_MASK (default 0, 9, 10) are compiled in (when do its workgroups start
 // and reach their last stage?) -- the full set changes the register allocation of the kernel it measures.
 #ifdef GSMCAL_DEVTIMING_LIGHT
-#define DEV_STAMP_ON(kid, i) ((kid) == GSMCAL_DEVTIMING_LIGHT && ((i) == 0 || (i) == 9 || (i) == 10))
+#ifndef GSMCAL_DEVTIMING_MASK
+#define GSMCAL_DEVTIMING_MASK 0x601          /* stamps 0, 9, 10 */
+#endif
+#define DEV_STAMP_ON(kid, i) ((kid) == GSMCAL_DEVTIMING_LIGHT && ((GSMCAL_DEVTIMING_MASK >> (i)) & 1))
 #else
 #define DEV_STAMP_ON(kid, i) true
 #endif

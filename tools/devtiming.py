@@ -27,12 +27,16 @@ def main():
     ap.add_argument("--mode", default="table")
     ap.add_argument("--light", type=int, default=-1,
                     help="kernel id (state.h KID_*): compile in only that kernel's stamps 0, 9, 10 (leaves its register allocation alone)")
+    ap.add_argument("--mask", default=None, help="with --light: bit mask of the stamps compiled in (default 0x601 = stamps 0, 9, 10)")
     args = ap.parse_args()
     global DEV
     flags = ["-DGSMCAL_DEVTIMING"]
     if args.light >= 0:
         DEV = DEV.replace("_dev.so", f"_dev_light{args.light}.so")
         flags.append(f"-DGSMCAL_DEVTIMING_LIGHT={args.light}")
+        if args.mask:
+            DEV = DEV.replace(".so", f"_{args.mask}.so")
+            flags.append(f"-DGSMCAL_DEVTIMING_MASK={args.mask}")
     src = os.path.join(PKG, "csrc", "gsmcal.hip")
     if not os.path.exists(DEV) or os.path.getmtime(DEV) < max(os.path.getmtime(os.path.join(PKG, "csrc", f)) for f in os.listdir(os.path.join(PKG, "csrc"))):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
