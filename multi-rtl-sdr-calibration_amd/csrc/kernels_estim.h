@@ -61,6 +61,13 @@ __device__ __forceinline__ PeakOut merge_peaks_coherent(const PeakOut* p, int NB
 // LDS: the gather carve (kernels_frontend.h); the window ends up in buf0 or buf1, the other buffer then
 // holds B[37][N2+1]; w37 | wN2 | P[2*hnl] follow the carve.  ~48 KB: three workgroups per CU.
 // ------------------------------------------------------------------------------------------------
+// Issue priority of this wave by the dispatch round of its workgroup (workgroups 0..255 / 256..511 / 512..: the first, second
+// and third to arrive on their CU).  The SIMDs issue oldest wave first, so of the three workgroups that share a CU the first
+// one dispatched runs ahead: in-kernel stamps show the streams of round 0 through every stage of k_post_chain_r 6-8 us before
+// those of round 2 (done at 45 against 57 us), and the launch ends with the slowest stream.  s_setprio overrides the age order.
+// Eight schedules tried (first half of the burst stage | its gate | SCH stage | last stage; E = oldest first, L = youngest
+// first): none 66.4 us, LLEE 64.8, LELE 64.4, LEEL 67.8, EELL 64.9, ELEL 66.2, ELLL 62.7, ELLE 62.0 -- the one used.
+#define PCR_PRIO(P0, P1, P2) { const unsigned rnd_ = (blockIdx.y * gridDim.x + blockIdx.x) >> 8; if (rnd_ == 0) __builtin_amdgcn_s_setprio(P0); else if (rnd_ == 1) __builtin_amdgcn_s_setprio(P1); else __builtin_amdgcn_s_setprio(P2); }
 #define BT_THREADS 512
 
 // ------------------------------------------------------------------------------------------------
@@ -354,6 +361,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     }
     BT_STAMP(3);
     if (!GATE) return;
+    if (state_in_lds) PCR_PRIO(0, 1, 2)                               // k_post_chain_r: from here through the SCH stage the last-dispatched workgroups issue first
     __syncthreads();
     // ---- SNR gate, FCCH_fine_correction.m:185-189: bins [0,hnl) and [nfft-hnl,nfft) only ----
     // exp(-1i*n*phase) = base[n/16] * pw[n%16]: accurate sincos only for the 16 powers and every 16th sample
@@ -1183,6 +1191,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 3);
     // ---- stage 1: bursts of the resampled stream (:141-165, :185-196) -> CARRIER_DECIDE + SCH window setup ----
+    PCR_PRIO(2, 1, 0)                                               // (the age order, made explicit; the gate inside turns it round)
     burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 4);
@@ -1218,6 +1227,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 9);
     // ---- stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124) ----
+    PCR_PRIO(2, 1, 0)
     burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 10);

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--mode", default="table")
     ap.add_argument("--light", type=int, default=-1,
                     help="kernel id (state.h KID_*): compile in only that kernel's stamps 0, 9, 10 (leaves its register allocation alone)")
+    ap.add_argument("--cflags", default="", help="extra compiler flags for the development build (its file name carries a hash of them)")
     ap.add_argument("--mask", default=None, help="with --light: bit mask of the stamps compiled in (default 0x601 = stamps 0, 9, 10)")
     args = ap.parse_args()
     global DEV
@@ -37,6 +38,10 @@ def main():
         if args.mask:
             DEV = DEV.replace(".so", f"_{args.mask}.so")
             flags.append(f"-DGSMCAL_DEVTIMING_MASK={args.mask}")
+    if args.cflags:
+        import hashlib
+        DEV = DEV.replace(".so", "_" + hashlib.sha1(args.cflags.encode()).hexdigest()[:8] + ".so")
+        flags += args.cflags.split()
     src = os.path.join(PKG, "csrc", "gsmcal.hip")
     if not os.path.exists(DEV) or os.path.getmtime(DEV) < max(os.path.getmtime(os.path.join(PKG, "csrc", f)) for f in os.listdir(os.path.join(PKG, "csrc"))):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
