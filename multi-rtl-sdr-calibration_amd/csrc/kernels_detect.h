@@ -1671,6 +1671,14 @@ __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
     return (size_t)FC_XP(wlen) * sizeof(cplx) + (r1 > e1 ? r1 : e1) + (r2 > e2 ? r2 : e2);
 }
 
+// Issue priority of this wave by the dispatch round of its workgroup (0..255 / 256..511 / 512..: first, second, third on its
+// CU).  The SIMDs issue oldest wave first: left alone, the first workgroup of a CU finishes at ~35 us, the third at 55, alone on
+// the CU for its last 10 us -- and the kernel ends with it.  Turning the order round between phases keeps the three closer
+// together and the CU full to the end: 55.3 -> 49.7 us (schedules tried, by phase group build | S + anchors | E(t) + slides +
+// certificate, E = oldest first, L = youngest first: ELE 54.1, LLL 50.7, ELL 50.9, LNL 50.0, LELEL 49.6, LEL 49.5).
+// (Only while the whole grid is resident, three workgroups per CU: a longer grid is dispatched continuously, there is no "round",
+// and the same switches cost the 1 024-stream step 1.3 %.)
+#define FC_PRIO(P0, P1, P2) if (gridDim.x * gridDim.y <= 768u) { const unsigned rnd_ = (blockIdx.y * gridDim.x + blockIdx.x) >> 8; if (rnd_ == 0) __builtin_amdgcn_s_setprio(P0); else if (rnd_ == 1) __builtin_amdgcn_s_setprio(P1); else __builtin_amdgcn_s_setprio(P2); }
 #define FC_PF 8   /* slide steps whose samples are fetched from LDS ahead of the arithmetic */
 // OV > 0: the reference geometry as compile-time constants (128*OV+1 shifts, 148*OV-point windows, NTAPS filter taps);
 // OV = 0: from the arguments.
@@ -1706,6 +1714,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     if (w >= sts[s].n_win) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    FC_PRIO(0, 1, 2)                                      // window build: youngest workgroup of the CU first (see FC_PRIO)
     if (fg.raw) {
         // The window straight from the raw bytes (raw2iq.m:6-8 + filter(coef,1,.), gather_core's level 0 with the same
         // order of operations), in passes of fg.per outputs staged through regions 1/2 (free until the tone estimate):
@@ -1801,6 +1810,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         __syncthreads();
     }
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 1);
+    FC_PRIO(2, 1, 0)                                      // choice of S and the anchors: oldest first
     // ---- S: the tone's bin from a 148-point spectrum of the window's middle nfft samples summed in groups of
     // ov (nfft = 148*ov, so the two frequency grids coincide; the channel filter keeps the signal inside the
     // decimated band).  Only the choice of S depends on this estimate, never the result: a poor choice just
@@ -1922,6 +1932,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     }
     __syncthreads();                                      // S and the tables are dead: E and sumS take their place
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 4);
+    FC_PRIO(0, 1, 2)                                      // E(t), slides, certificate: youngest first
     // ---- E(t): E(0) by a block reduction, then a block scan of g[q] = |x[q+nfft]|^2 - |x[q]|^2 ----
     {
         double e0 = 0.0;
