@@ -254,6 +254,8 @@ __device__ __forceinline__ void coarse_twiddles(cplx* tw, int fft_len, int tid, 
 // grid (ceil(nwin/256), S), block 256.  FFT16: the reference geometry (16-point windows, radix-2 in registers); the
 // other instance serves any window length 2..64 by direct DFTs (a called function: keeping it out of the FFT16
 // instance keeps that one free of scratch memory and within 128 registers -- four blocks per CU).
+// issue priority by dispatch round (four workgroups per CU; only while the whole grid is resident)
+#define CS_PRIO(P0, P1, P2, P3) if (gridDim.x * gridDim.y <= 1024u) { const unsigned rnd_ = (blockIdx.y * gridDim.x + blockIdx.x) >> 8; if (rnd_ == 0) __builtin_amdgcn_s_setprio(P0); else if (rnd_ == 1) __builtin_amdgcn_s_setprio(P1); else if (rnd_ == 2) __builtin_amdgcn_s_setprio(P2); else __builtin_amdgcn_s_setprio(P3); }
 #define CS_TILE 1024          /* k_coarse_snr<.,true>: most windows past the moving search one workgroup screens */
 #define CS_SNR_THREADS 256
 // Screening level test of one window for k_coarse_snr (see there): |r1|^2 < g(rho_X)^2 r0^2 proves SNR < X dB.
@@ -325,6 +327,7 @@ __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((
     const int tid = threadIdx.x;
     if (!FFT16) coarse_twiddles(tw, g.fft_len, tid, 256);
     __syncthreads();
+    CS_PRIO(0, 1, 2, 3)                                  // staging and screening: the youngest workgroup of the CU first (see FC_PRIO in k_fine_cert's header)
     const long i = (long)blockIdx.x * 256 + tid;
     // the stream's mean comes from the front kernel's partial byte sums: requested by the first wave BEFORE the samples below, so
     // that the two round trips to L2 overlap (a tenth of this kernel's time); summed after them
@@ -399,6 +402,7 @@ __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((
             }
         }
         if (SCREEN) __syncthreads();
+        CS_PRIO(3, 2, 1, 0)                              // the spectra: oldest first (16.7 -> 16.0 us at 64 streams)
         // FFT passes: the moving search's window of each thread, then the survivors (~45 per tile: the first wave)
         const int cnt = SCREEN ? sh_cnt : 0;
         for (int k0 = -256; k0 < cnt; k0 += 256) {

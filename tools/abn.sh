@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development aid: several builds of libgsmcal in one GPU session: tools/abn.sh lib1.so lib2.so ... (post-chain time + step)
+# Development aid: several builds of libgsmcal in one GPU session: tools/abn.sh lib1.so lib2.so ... (step + kernel times)
 mkdir -p gpurun_out; : > gpurun_out/abn.txt
 for rep in 1 2; do
   for L in "$@"; do
@@ -8,7 +8,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); k = d.get('kernels_ms_per_step_untimed_pass') or {}
-        print('$L'.split('/')[-1], d['ms_per_step'], {a: b for a, b in k.items() if 'post_chain' in a or 'cert' in a})
+        print('$L'.split('/')[-1], d['ms_per_step'], ' '.join('%s=%.1f' % (a.strip('()').split('<')[0][2:], 1e3 * b) for a, b in k.items()))
 " >> gpurun_out/abn.txt
   done
 done
