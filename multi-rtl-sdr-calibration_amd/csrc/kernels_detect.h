@@ -1666,7 +1666,7 @@ struct FusedGather {
 // staging bytes of one pass: padded complex input | coefficients
 __host__ inline size_t fc_stage_bytes(int per, int ntaps) {
     const int span8 = per + ntaps + 8;
-    return (size_t)(span8 + span8 / 4 + 1) * sizeof(cplx) + (size_t)((ntaps + 1) & ~1) * sizeof(double);
+    return (size_t)(span8 + span8 / 4 + 1) * sizeof(cplx) + (size_t)fir_taps_padded(ntaps) * sizeof(double);
 }
 __host__ inline size_t fc_lds_bytes(int nshift, int nfft) {
     const int nstep = nshift - 1, wlen = nstep + nfft, B = fc_gcd64(nfft);
@@ -1732,7 +1732,7 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         double* c_s = (double*)(xq + xs_pad(per + ntp + 8) + 1);
         const unsigned short* base = (const unsigned short*)(fg.raw + (size_t)s * fg.raw_stride);
         cplx* wout = fg.win_out + (size_t)s * win_stream_stride + (size_t)w * win_stride;
-        for (int i = tid; i < ntp; i += nthr) c_s[i] = fg.coef[i];
+        fir_stage_taps(c_s, fg.coef, ntp, tid, nthr);
         // raw chunk `tid` of a pass (8 samples, 16-byte aligned), fetched one pass ahead so the loads overlap the FIR of
         // the previous one; samples outside the stream read as 0 and are zeroed again after the mean is subtracted
         const long ao = (long)(((uintptr_t)base >> 1) & 7);

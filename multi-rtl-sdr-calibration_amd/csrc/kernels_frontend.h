@@ -616,11 +616,17 @@ __device__ __forceinline__ int xs_pad(int p) { return p + (p >> 2); }
 // ------------------------------------------------------------------------------------------------
 // UNR: trips of the four-tap loop the compiler may overlap (2: the next trip's LDS reads under this trip's FMAs, ~20 more
 // registers; 1 where the caller has none to spare).
+// taps of fir4_lds in LDS: rev[j] = coef[ntaps-1-j] (oldest tap first), zero-padded to a multiple of four
+__host__ __device__ inline int fir_taps_padded(int ntaps) { return (ntaps + 3) & ~3; }
+__device__ __forceinline__ void fir_stage_taps(double* c_s, const double* __restrict__ coef, int ntaps, int first, int step) {
+    for (int i = first; i < fir_taps_padded(ntaps); i += step) c_s[i] = i < ntaps ? coef[ntaps - 1 - i] : 0.0;
+}
 template <int NTP, bool PAD = true, int UNR = 2>
 __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const double* __restrict__ c_s, int i0, int ntp_rt,
                                          cplx* y0, cplx* y1, cplx* y2, cplx* y3) {
 #define XSP(p_) (PAD ? xs_pad(p_) : (p_))
     const int ntp = NTP > 0 ? NTP : ntp_rt;
+    const int ntp4 = (ntp + 3) & ~3;
     double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
     cplx w0 = xq[XSP(i0)], w1 = xq[XSP(i0 + 1)], w2 = xq[XSP(i0 + 2)], w3 = xq[XSP(i0 + 3)];
 #define GSMCAL_FIR_TAP(C, A, B, D, E)                                   \
@@ -629,27 +635,20 @@ __device__ __forceinline__ void fir4_lds(const cplx* __restrict__ xq, const doub
     ar2 = fma(C, D.x, ar2); ai2 = fma(C, D.y, ai2);                     \
     ar3 = fma(C, E.x, ar3); ai3 = fma(C, E.y, ai3);
     // four taps per trip: the next four samples are one aligned, contiguous 64-byte group (i0 is a multiple of 4),
-    // fetched together.  Every accumulator still takes its taps in the same order (oldest first), so the sums are
-    // bit-identical to a one-tap loop.
-    int t = 0;
+    // fetched together, and so are the four taps (c_s holds them REVERSED -- oldest tap first -- and zero-padded to a multiple
+    // of four: fir_stage_taps; two 16-byte reads per trip instead of four 8-byte ones, and no remainder loop:
+    // fma(0, x, acc) = acc for the finite samples the callers stage behind the span).  Every accumulator still takes its
+    // taps in the same order (oldest first), so the sums are bit-identical to a one-tap loop.
 #pragma unroll UNR
-    for (; t + 4 <= ntp; t += 4) {
+    for (int t = 0; t < ntp4; t += 4) {
         const cplx* nx = xq + XSP(i0 + t + 4);
-        const double c0 = c_s[ntp - 1 - t], c1 = c_s[ntp - 2 - t], c2 = c_s[ntp - 3 - t], c3 = c_s[ntp - 4 - t];   // (before the samples: LDS returns in order, and the first taps need only these)
+        const double c0 = c_s[t], c1 = c_s[t + 1], c2 = c_s[t + 2], c3 = c_s[t + 3];   // (before the samples: LDS returns in order, and the first taps need only these)
         const cplx n0s = nx[0], n1s = nx[1], n2s = nx[2], n3s = nx[3];
         GSMCAL_FIR_TAP(c0, w0, w1, w2, w3)
         GSMCAL_FIR_TAP(c1, w1, w2, w3, n0s)
         GSMCAL_FIR_TAP(c2, w2, w3, n0s, n1s)
         GSMCAL_FIR_TAP(c3, w3, n0s, n1s, n2s)
         w0 = n0s; w1 = n1s; w2 = n2s; w3 = n3s;
-    }
-    int p = i0 + t + 3;
-    for (; t < ntp; ++t) {
-        const double c = c_s[ntp - 1 - t];
-        GSMCAL_FIR_TAP(c, w0, w1, w2, w3)
-        w0 = w1; w1 = w2; w2 = w3;
-        ++p;
-        w3 = xq[XSP(p)];
     }
 #undef GSMCAL_FIR_TAP
 #undef XSP
@@ -675,7 +674,7 @@ __host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind
     if (xs_n > r1) r1 = xs_n;
     g.off_region1 = g.bufn * 16;
     g.off_coef = g.off_region1 + r1 * 16;
-    g.off_raw = g.off_coef + (size_t)((ntaps + 1) & ~1) * 8;
+    g.off_raw = g.off_coef + (size_t)fir_taps_padded(ntaps) * 8;
     g.total = (g.off_raw + ((span_max + 7) & ~(size_t)7) * 2 + 15) & ~(size_t)15;
     // the rotator table of a derotation level lives where the raw bytes were (dead once level 0 exists); array sources
     // have no raw region, so it is appended there
@@ -717,7 +716,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
     __shared__ long pl_l0off;
     // ... which meanwhile fetch the filter taps
     if (a.src_kind != SRC_ARR && NT > 64 && tid >= 64)
-        for (int i = tid - 64; i < a.ntaps; i += NT - 64) c_s[i] = a.coef[i];
+        fir_stage_taps(c_s, a.coef, a.ntaps, tid - 64, NT - 64);
     if (tid < 64) {
         // (loads that bypass the vector L1: inside a fused launch these fields were rewritten by another workgroup's
         // decision step -- write-through stores -- since this CU may last have read them; L2-served, same cost as plain)
@@ -780,7 +779,7 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
         }
     }
     if (a.src_kind != SRC_ARR && NT <= 64)
-        for (int i = tid; i < a.ntaps; i += NT) c_s[i] = a.coef[i];
+        fir_stage_taps(c_s, a.coef, a.ntaps, tid, NT);
     GC_STAMP(15);
     __syncthreads();
     const int L = pl_L;
