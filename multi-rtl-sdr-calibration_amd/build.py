@@ -18,6 +18,10 @@ def _deps():
 
 
 def needs_build():
+    if os.environ.get("GSMCAL_LIB"):                 # another build was asked for by name: it is loaded as it is, never rebuilt
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"GSMCAL_LIB={LIB} does not exist")
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
