@@ -204,7 +204,7 @@ __device__ __forceinline__ int burst_gather_fast(const StreamState* __restrict__
     return 1;
 }
 #define BT_STAMP(i) DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, i)
-template <int GATE>
+template <int GATE, int FIR_UNR = 1>
 __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, const GatherArgs& a, int nfft,
                                                 const cplx* __restrict__ tw_g, int ov, int prior_mode,
                                                 unsigned char* smem, double* res = nullptr,    // res: {fo, snr} instead of the stores into the state
@@ -220,7 +220,7 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
     if (fast < 0) return;                                           // block-uniform, like the two below
     cplx* xs = (cplx*)smem;                                         // nfft samples of the burst, in LDS
     if (!fast) {
-        xs = gather_core<BT_THREADS, GATE ? KID_BT1 : KID_BT0>(sts, a, smem, w, s, true);
+        xs = gather_core<BT_THREADS, GATE ? KID_BT1 : KID_BT0, FIR_UNR>(sts, a, smem, w, s, true);
         if (!xs) return;
         __syncthreads();
     }
@@ -421,12 +421,13 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
 // Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge (:59).
 // ------------------------------------------------------------------------------------------------
 #define SCH_PARTS 4
+template <int FIR_UNR = 1>
 __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, const GatherArgs& a,
                                                 const cplx* __restrict__ ts, int len_ts, int nshift,
                                                 unsigned char* smem, double* res = nullptr) {   // res: {SCH_pos, edge flag}
     const int s = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    cplx* xs = gather_core<512>(sts, a, smem, w, s, true);
+    cplx* xs = gather_core<512, -1, FIR_UNR>(sts, a, smem, w, s, true);
     if (!xs) return;
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 1);
     const GatherCarve gc = gather_carve(a.len, a.level, a.src_kind, a.ntaps, true, a.pad != 0);
@@ -956,7 +957,7 @@ k_burst_tone(StreamState* __restrict__ sts, GatherArgs a_in, int nfft_rt, const 
     GatherArgs a = a_in;
     const int nfft = OV > 0 ? 148 * OV : nfft_rt, ov = OV > 0 ? OV : ov_rt;
     if (OV > 0) { a.len = 148 * OV; a.ntaps = NTAPS; a.src_kind = SRC_RAW; a.tiles = 0; a.level = GATE ? 1 : 3; }   // (the chain on raw bytes from level 0: bursts at levels 1 and 3)
-    burst_tone_body<GATE>(sts, a, nfft, tw_g, ov, prior_mode, smem);
+    burst_tone_body<GATE, (OV > 0 ? 2 : 1)>(sts, a, nfft, tw_g, ov, prior_mode, smem);
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 5);
     stream_tail(sts, tail, smem, GATE ? KID_BT1 : KID_BT0);
     DEV_STAMP(GATE ? KID_BT1 : KID_BT0, blockIdx.y * gridDim.x + blockIdx.x, 6);
@@ -969,7 +970,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
     GatherArgs a = a_in;
     const int len_ts = OV > 0 ? LT : len_ts_rt, nshift = OV > 0 ? 11 * OV + 1 : nshift_rt;
     if (OV > 0) { a.len = 11 * OV + LT; a.ntaps = NTAPS; a.src_kind = SRC_RAW; a.tiles = 0; a.level = 2; }
-    window_sch_body(sts, a, ts, len_ts, nshift, smem);
+    window_sch_body<(OV > 0 ? 2 : 1)>(sts, a, ts, len_ts, nshift, smem);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 3);
     stream_tail(sts, tail, smem, KID_SCH);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 4);
@@ -1213,7 +1214,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     // ---- stage 2: SCH_corr_rate_correction.m:45-55 -> SCH_DECIDE (:59-181) + post-SCH window setup ----
     const int n_sch_win = sh->n_win;
     PCR_PRIO(0, 1, 2)                                               // (the deciding wave returns to its round's priority)
-    window_sch_body(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
+    window_sch_body<(OV > 0 ? 2 : 1)>(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 7);
     pcr_exchange(mine_x + 4 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);

@@ -692,7 +692,9 @@ __host__ __device__ inline GatherCarve gather_carve(int len, int level, int kind
 // stays in LDS and its address is returned (nullptr if this block has no window).
 // The block's window index is `widx`, its stream `s`.  smem: the dynamic LDS base, carved as
 //   buf0 | buf1 (aliased with the padded complex input xs) | coef | raw ushorts     (GatherCarve).
-template <int NT, int KID = -1>
+// FIR_UNR: trips of the raw-source FIR loop the compiler may overlap (fir4_lds' UNR): 2 where the caller's tap count is a
+// compile-time constant and its register budget allows (the reference-geometry instantiations), else 1.
+template <int NT, int KID = -1, int FIR_UNR = 1>
 __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts, const GatherArgs& a,
                                              unsigned char* smem, int widx, int s, bool to_lds) {
 #define GC_STAMP(i) do { if (KID >= 0) DEV_STAMP(KID, blockIdx.y * gridDim.x + blockIdx.x, i); } while (0)
@@ -838,8 +840,8 @@ __device__ __forceinline__ cplx* gather_core(const StreamState* __restrict__ sts
             // (the run-time-count form, one trip at a time: the two-trip forms need ~20 more registers than the 80 the fused
             // per-burst kernels have -- scratch in the loop, and a kernel with ANY scratch starts its workgroups later;
             // k_fine_cert, at 108 registers, uses fir4_lds<47>)
-            if (compact) fir4_lds<0, false, 1>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
-            else fir4_lds<0, true, 1>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            if (compact) fir4_lds<0, false, FIR_UNR>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+            else fir4_lds<0, true, FIR_UNR>(xs, c_s, i0, ntp, &y0, &y1, &y2, &y3);
             out0[i0] = y0;
             if (i0 + 1 < cnt0) out0[i0 + 1] = y1;
             if (i0 + 2 < cnt0) out0[i0 + 2] = y2;
