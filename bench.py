@@ -536,6 +536,9 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
                                   "what": "64 distinct streams drawn like tests/sweep_parity.py (every 5th at 5-15 dB, every 7th up to "
                                           "+-300 ppm sampling error, every 11th without BCCH, every 13th up to +-60 ppm carrier "
                                           "error), nothing pre-selected"}
+            if not args.no_kernel_events:
+                prof = event_pass(ctx, lambda: c2.launch(0), K, torch, dev)
+                sub["mixed_batch"]["kernels_ms_per_step_untimed_pass"] = {k: round(v_[0] / K, 4) for k, v_ in sorted(prof.items(), key=lambda kv: -kv[1][0])}
             del c2, mt
         except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
             sub["mixed_batch"] = {"error": repr(e)}
