@@ -522,7 +522,6 @@ int run_sch(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, int
     const int wl = g.sch_nshift - 1 + len_ts;
     const long wstride = g.fine_wlen > wl ? g.fine_wlen : wl, sstride = (long)H * wstride;
     RET_IF(ensure(c, c->cur->win, (size_t)S * sstride * sizeof(cplx)));
-    cplx* win = (cplx*)c->cur->win.p;
     const StepArgs sa = step_args(c, g, H, len_ts);
     if (!setup_done) LAUNCH(c, k_step<STEP_SCH_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
     {
@@ -548,7 +547,6 @@ int run_post(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     RET_IF(ensure(c, c->cur->peaks, (size_t)S * H * g.NB * sizeof(PeakOut)));
     RET_IF(ensure_twiddles(c, g.nfft));
     cplx* win = (cplx*)c->cur->win.p;
-    PeakOut* peaks = (PeakOut*)c->cur->peaks.p;
     StepArgs sa = step_args(c, g, H, 0);
     sa.table = table; sa.pos_info_out = pos_info_out; sa.r_len_out = r_len_out;
     if (!setup_done) LAUNCH(c, k_step<STEP_POST_SETUP>, dim3(S), dim3(64), 0, st, sa, 0, lvl);
