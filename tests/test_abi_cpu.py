@@ -172,3 +172,22 @@ def test_params_defaults_are_the_reference_literals(gsmcal_mod):
     assert (p.min_hits, p.fine_max_offset, p.fine_max_ppm, p.fine_gate_snr_db) == (5, 64, 4000.0, 5.0)   # FCCH_fine_correction.m:12,30,83,192
     assert (p.sch_max_offset, p.sch_max_ppm, p.post_min_bcch) == (8, 400.0, 4)               # SCH_corr..m:36,94; carrier_correct..m:15
     assert (p.scan_min_hits, p.scan_spacing, p.scan_spacing_idle, p.scan_tol) == (3, 12500.0, 13750.0, 50.0)   # ..FCCH_scanner.m:169-176
+
+
+def test_named_library_is_never_rebuilt_and_must_exist(tmp_path):
+    """GSMCAL_LIB names another build of the library (tools/ab.sh, tools/devtiming.py): it is loaded as it is -- a missing
+    file is an error, not a reason to compile the current sources into that name (which made two 'different' builds equal)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import importlib.util, os\n"
+            "spec = importlib.util.spec_from_file_location('b', os.path.join(%r, 'multi-rtl-sdr-calibration_amd', 'build.py'))\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "try:\n"
+            "    b.needs_build(); print('no error')\n"
+            "except RuntimeError as e:\n"
+            "    print('raised', e)\n") % (ROOT, ROOT)
+    env = dict(os.environ, GSMCAL_LIB=str(tmp_path / "absent.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("raised") and "absent.so" in out
+    assert not (tmp_path / "absent.so").exists()
