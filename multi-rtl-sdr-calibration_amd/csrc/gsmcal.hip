@@ -2092,17 +2092,18 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
         std::vector<ChunkRec> rec((size_t)S * H * nchunk);
         if (L.chunkrec.cap >= rec.size() * sizeof(ChunkRec)) {
             HIPCHK(c, hipMemcpy(rec.data(), L.chunkrec.p, rec.size() * sizeof(ChunkRec), hipMemcpyDeviceToHost));
-            int hist[20] = {0}, nwin = 0, cand_hist[8] = {0}, win_with_cand = 0;
+            int hist[20] = {0}, nwin = 0, cand_hist[8] = {0}, win_with_cand = 0, n_open_chunks = 0;
             for (int s = 0; s < S; ++s)
                 for (int w = 0; w < H && w < st[s].n_fine_ws; ++w) {
                     const FineCert& f = fc[(size_t)s * H + w];
-                    ++nwin; ++hist[f.nch < 19 ? f.nch : 19];
+                    ++nwin; ++hist[f.nch < 19 ? f.nch : 19]; n_open_chunks += f.nch;
                     int tot = 0;
-                    for (int k = 0; k < f.nch; ++k) { const int cnt = rec[((size_t)s * H + w) * nchunk + k].count; tot += cnt < 0 ? 100 : cnt; }
+                    for (int k = 0; k < f.nch; ++k) { const int cnt = rec[((size_t)s * H + w) * nchunk + (k < f.nch - f.nsuf ? k : nchunk - f.nch + k)].count; tot += cnt < 0 ? 100 : cnt; }
                     if (f.nch > 0) { ++cand_hist[tot < 7 ? tot : 7]; if (tot) ++win_with_cand; }
                 }
             fprintf(stderr, "certificate: %d windows; open chunks per window:", nwin);
             for (int i = 0; i < 20; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+            fprintf(stderr, "  (%d open chunks in all)", n_open_chunks);
             fprintf(stderr, "\n  candidates the chunk sweep handed to the exact pass, per window with open chunks:");
             for (int i = 0; i < 8; ++i) if (cand_hist[i]) fprintf(stderr, " %d%s:%d", i, i == 7 ? "+" : "", cand_hist[i]);
             fprintf(stderr, "  (%d windows with any)\n", win_with_cand);

@@ -1283,7 +1283,10 @@ __device__ __forceinline__ cplx anchor_dft(const cplx* xw, int k, const cplx* __
 }
 
 // result of k_fine_cert for one window (see below)
-struct FineCert { double p; int t, k, a, b; int nch; int pad; };
+// nch open chunks: the first nch - nsuf of the window (its uncertified prefix of shifts) and the last nsuf (its uncertified suffix)
+struct FineCert { double p; int t, k, a, b; int nch; int nsuf; };
+// chunk id of the j-th open chunk of a window
+__device__ __forceinline__ int fc_open_chunk(int j, int nch, int nsuf, int nchunk) { return j < nch - nsuf ? j : nchunk - nch + j; }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -1499,7 +1502,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
     const int nstep = nshift - 1;
     const int nchunk = (nstep + FS_CHUNK - 1) / FS_CHUNK;
     FineCert fc;
-    fc.p = -1.0; fc.t = 0x7fffffff; fc.k = 0x7fffffff; fc.nch = nchunk;
+    fc.p = -1.0; fc.t = 0x7fffffff; fc.k = 0x7fffffff; fc.nch = nchunk; fc.nsuf = 0;
     if (cert) {
         fc = cert[(size_t)s * H + w];
         if (fc.nch == 0) {                                // fully certified window: the certificate IS the answer
@@ -1507,13 +1510,14 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
             return;
         }
     }
-    const int nopen = fc.nch;
+    const int nopen = fc.nch, nsuf = fc.nsuf;             // open chunk j has id fc_open_chunk(j, nopen, nsuf, nchunk); its record sits in slot j
     // the open chunks' records (256 B each) come into LDS with one round of coalesced loads; the window's place is free
     ChunkRec* r = (ChunkRec*)smem;
     {
         const uint4* src = (const uint4*)(rec + ((size_t)s * H + w) * nchunk);
         uint4* dst = (uint4*)r;
-        for (int i = tid; i < nopen * (int)(sizeof(ChunkRec) / 16); i += FVT) dst[i] = src[i];
+        constexpr int Q = (int)(sizeof(ChunkRec) / 16);
+        for (int i = tid; i < nopen * Q; i += FVT) { const int j = i / Q; dst[i] = src[fc_open_chunk(j, nopen, nsuf, nchunk) * Q + (i - j * Q)]; }
     }
     if (tid == 0) { n_items = 0; n_over = 0; }
     __syncthreads();
@@ -1532,7 +1536,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
         const ChunkCand cc = r[c].cand[q];
         if (sqrt((double)cc.p) + r[c].E >= L) {
             const int idx = atomicAdd(&n_items, 1);
-            if (idx < FV_MAX_ITEMS) items[idx] = (cc.k << 8) | c;
+            if (idx < FV_MAX_ITEMS) items[idx] = (cc.k << 8) | fc_open_chunk(c, nopen, nsuf, nchunk);
         }
     }
     __syncthreads();
@@ -1557,7 +1561,7 @@ __device__ __forceinline__ void fine_verify_body(const StreamState* __restrict__
                 __syncthreads();
                 for (int i = tid; i < ni; i += FVT) {
                     const long g = base + i;
-                    items[i] = ((int)(g % nfft) << 8) | (int)(g / nfft);
+                    items[i] = ((int)(g % nfft) << 8) | fc_open_chunk((int)(g / nfft), nopen, nsuf, nchunk);
                 }
                 __syncthreads();
             }
@@ -2088,14 +2092,19 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
     __syncthreads();
     if (tid == 0) {
         FineCert o;
-        o.p = best; o.t = bt; o.k = bk; o.a = sh_a; o.b = sh_b; o.pad = 0;
-        const int a = sh_a;
-        if (sh_b < nstep || a > bt) o.nch = nchunk;       // a suffix (or everything) is open: sweep the whole window
-        else o.nch = a == 0 ? 0 : (a == 1 ? 1 : (a - 2) / FS_CHUNK + 1);   // chunk c holds shifts 64c+1..64c+64 (+ shift 0)
+        o.p = best; o.t = bt; o.k = bk; o.a = sh_a; o.b = sh_b;
+        // every uncertified shift lies in the prefix [0, a) or in the suffix (b, nstep] (the certificate's loop above): only
+        // the chunks that hold those are swept.  Chunk c holds shifts 64c+1 .. 64c+64 (+ shift 0 in chunk 0).  (Round 3: a
+        // window with any suffix open used to be swept whole -- 560 chunks instead of 165 on the 64 mixed streams of bench.py.)
+        const int a = sh_a, b = sh_b;
+        int npre = a == 0 ? 0 : (a == 1 ? 1 : (a - 2) / FS_CHUNK + 1);
+        int nsuf = b < nstep ? nchunk - b / FS_CHUNK : 0;  // shift b+1 is the first of the suffix: chunk b/64
+        if (npre + nsuf > nchunk) { npre = nchunk; nsuf = 0; }
+        o.nch = npre + nsuf; o.nsuf = nsuf;
         cert[(size_t)s * H + w] = o;
         if (o.nch > 0) {                                  // work list of k_fine_chunk
             const int base = atomicAdd(n_items, o.nch);
-            for (int i = 0; i < o.nch; ++i) items[base + i] = ((s * H + w) << 8) | i;
+            for (int i = 0; i < o.nch; ++i) items[base + i] = ((s * H + w) << 8) | fc_open_chunk(i, o.nch, nsuf, nchunk);
         }
     }
     DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 7);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--light", type=int, default=-1,
                     help="kernel id (state.h KID_*): compile in only that kernel's stamps 0, 9, 10 (leaves its register allocation alone)")
     ap.add_argument("--cflags", default="", help="extra compiler flags for the development build (its file name carries a hash of them)")
+    ap.add_argument("--mixed", action="store_true", help="streams drawn like bench.py's mixed_batch (low SNR, large ppm, carriers without BCCH)")
     ap.add_argument("--mask", default=None, help="with --light: bit mask of the stamps compiled in (default 0x601 = stamps 0, 9, 10)")
     args = ap.parse_args()
     global DEV
@@ -62,7 +63,12 @@ def main():
     coef = np.ascontiguousarray(synth.fir1(30 if scan else 46, 200e3 / synth.FS))
     ts = np.ascontiguousarray(synth.sch_training_sequence())
     cf = np.full(D, 957.4e6)
-    distinct = np.stack([synth.make_stream(dongle=i, num_frames=args.frames)[0] for i in range(nd)])
+    if args.mixed:                                        # the unselected distribution of bench.py's mixed_batch sub-result
+        import bench
+        kws = bench.mixed_kwargs(nd, 5000)
+        distinct = np.stack([synth.make_stream(dongle=5000 + i, num_frames=args.frames, **kws[i])[0] for i in range(nd)])
+    else:
+        distinct = np.stack([synth.make_stream(dongle=i, num_frames=args.frames)[0] for i in range(nd)])
     raw_t = torch.from_numpy(distinct).to(dev).repeat(((D + nd - 1) // nd, 1))[:D].contiguous()
     table_t = torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev)
     pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
