@@ -74,7 +74,8 @@ def gen_streams(jobs):
     """Synthetic captures for `jobs` = [(dongle, frames, kwargs)], one worker process per host core (0.5 s of NumPy per
     stream).  Called BEFORE this process touches the GPU: the workers are forked from a process without HIP state."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(ncpu, 32, len(jobs)))
+    world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    workers = max(1, min(ncpu // world, 32, len(jobs)))      # under torchrun every rank of the node generates at the same time
     if workers == 1:
         return [_gen_one(j) for j in jobs]
     from concurrent.futures import ProcessPoolExecutor

@@ -255,11 +255,15 @@ int gsmcal_comm_init_file(gsmcal_ctx* ctx, const char* path, int world, int rank
 /* The id file is run-specific: it carries a magic word and a 64-bit nonce next to the id.  Rank 0 removes whatever sits at
  * `path` before it generates the id, publishes the new file by an atomic rename, and removes it again once the communicator
  * is up (ncclCommInitRank returns only after every rank has joined), so a file survives only a crashed bootstrap.  Readers
- * accept nothing but a complete file with the right magic AND the caller's nonce; with nonce 0 ("none", what
- * gsmcal_comm_init_file passes unless GSMCAL_COMM_NONCE is set in the environment) they instead refuse files older than
- * GSMCAL_COMM_STALE_S seconds (default 120).  Give every launch its own nonce (job id, launcher pid, start time). */
+ * accept nothing but a complete file with the right magic AND the caller's nonce; with nonce 0 ("none") they instead
+ * refuse files older than GSMCAL_COMM_STALE_S seconds (default 120) -- unsafe for a relaunch inside that window, which
+ * would accept the dead launch's id.  Give every launch its own nonce (job id, launcher pid, start time).
+ * gsmcal_comm_init_file derives one itself: GSMCAL_COMM_NONCE if set, else a hash of the launcher's run / job id
+ * (TORCHELASTIC_RUN_ID, SLURM_JOB_ID, PBS_JOBID, LSB_JOBID) and MASTER_ADDR:MASTER_PORT; 0 only if none of these exist. */
 int gsmcal_comm_init_file_nonce(gsmcal_ctx* ctx, const char* path, unsigned long long nonce, int world, int rank,
                                 gsmcal_comm** out);
+/* The nonce gsmcal_comm_init_file derives from the environment (see above); 0 = the environment identifies no launch. */
+unsigned long long gsmcal_comm_default_nonce(void);
 /* The file protocol alone (no GPU, no RCCL; what the two functions above run before ncclCommInitRank): rank 0 publishes
  * id_inout, the other ranks wait up to timeout_s seconds for it and receive it in id_inout.  GSMCAL_E_ARG on time-out.
  * gsmcal_comm_id_file_remove: rank 0's clean-up after the communicator is up. */

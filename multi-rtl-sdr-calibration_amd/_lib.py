@@ -73,6 +73,7 @@ SIGNATURES = {
     "gsmcal_comm_init_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmcal_last_batch_snr": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_long, c_long_p, c_long_p]),
     "gsmcal_comm_init_file_nonce": (C.c_int, [C.c_void_p, C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmcal_comm_default_nonce": (C.c_ulonglong, []),
     "gsmcal_comm_id_file_exchange": (C.c_int, [C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_double]),
     "gsmcal_comm_id_file_remove": (C.c_int, [C.c_char_p]),
     "gsmcal_comm_destroy": (None, [C.c_void_p]),

@@ -51,13 +51,12 @@ struct ProfRec {
 #define MAX_LANES 32
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr, xch;
+    DevBuf state, dec, win, peaks, snrbuf, x0, chunkrec, openlist, cert, partial, tailctr, postctr, xch, xepoch;
     int npartial = 0;           // front-kernel blocks per stream of the last front_fused()
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr;   // scanner pipeline: this stage's front kernel has finished
     int lo = 0, n = 0;          // streams [lo, lo+n) of the last batch
     long snr_stride = 0, snr_nmove = 0; // SNR table of the last coarse(): entries per stream, and how many of them are the moving search's
-    int xch_S = 0, xch_H = 0;          // geometry the exchange block / launch counters of k_post_chain_r were cleared for
     int win_l0_len = 0, win_l0_H = 0;  // > 0: `win` holds the fine search's level-0 windows (this length each, H per stream) of the call in progress
 };
 
@@ -105,6 +104,9 @@ struct gsmcal_ctx {
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
+    struct OccEntry { int variant; size_t lds; int blocks; };
+    std::vector<OccEntry> occ_cache;  // post_chain_blocks_per_cu()
+    int post_slots_cap = 0;           // GSMCAL_POST_SLOTS: upper bound on the fused tail's workgroups per CU (0: the occupancy calculator's figure)
     gsmcal_params params;           // thresholds (defaults = the reference's literals)
     unsigned long params_epoch = 0; // bumped by gsmcal_set_params: captured graphs carry the old values
     // shared workspace
@@ -348,6 +350,23 @@ StepArgs step_args(gsmcal_ctx* c, const Geom& g, int H, int len_ts) {
     return a;
 }
 
+// Workgroups of the fused tail (k_post_chain_r<8,512,47> | k_post_chain_r<0,0,0> | k_post_chain) that fit one CU at this
+// dynamic LDS size, from the occupancy calculator of the runtime (registers, LDS granules, wave slots of the compiled kernel);
+// cached per (variant, LDS size).  0: the query failed -- the four-launch tail is used.
+int post_chain_blocks_per_cu(gsmcal_ctx* c, int variant, size_t lds) {
+    for (const auto& e : c->occ_cache)
+        if (e.variant == variant && e.lds == lds) return e.blocks;
+    int nb = 0;
+    hipError_t r;
+    if (variant == 0) r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_post_chain_r<8, 512, 47>, PC_THREADS, lds);
+    else if (variant == 1) r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_post_chain_r<0, 0, 0>, PC_THREADS, lds);
+    else r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_post_chain, PC_THREADS, lds);
+    if (r != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    if (c->post_slots_cap > 0 && nb > c->post_slots_cap) nb = c->post_slots_cap;
+    c->occ_cache.push_back({variant, lds, nb});
+    return nb;
+}
+
 // ---- FCCH_fine_correction body (input at level lvl; creates levels lvl+1 (lerp), lvl+2 (mix)) ----
 // setup_done: the window setup already ran at the end of k_coarse_scan (batch path).
 // next_sch_lvl >= 0: also run SCH_corr_rate_correction's window setup in the last decision launch.
@@ -429,35 +448,43 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             const size_t sch_scratch = (size_t)(len_ts + g.sch_nshift * SCH_PARTS) * sizeof(cplx) + (size_t)g.sch_nshift * sizeof(double);
             // replicated decisions (k_post_chain_r): the state copy stays in LDS in front of the stages' work area, and
             // the burst stages stage their (rare) raw-byte fallback without bank padding so that three workgroups still fit a CU
-            const bool repl = c->post_repl && H <= 32;
+            const bool repl = c->post_repl && H <= MAXH;
             size_t lds = vlds;
             lds = std::max(lds, fused_lds(src, lvl + 1, g.nfft, burst_scratch(g), repl));
             lds = std::max(lds, fused_lds(src, lvl + 2, wl_sch, sch_scratch));
             lds = std::max(lds, fused_lds(src, lvl + 3, g.nfft, burst_scratch(g), repl));
             lds = std::max(lds, (sizeof(StreamState) + 15) & ~(size_t)15);
             if (repl) lds += PCR_STATE_BYTES;
-            // only while every workgroup of the launch is resident at once (three 512-thread workgroups per CU): a workgroup
-            // waiting at a stream barrier holds its slot, which costs nothing in the latency regime (64 streams: 0.234 vs
-            // 0.237 ms per step) and a fifth of the throughput beyond it (256 streams: 0.73 vs 0.63 ms; 1024: 2.53 vs 2.13)
+            const bool ref_geom = g.ov == 8 && g.nfft == 148 * 8 && g.fine_nshift == 128 * 8 + 1 && g.sch_nshift == 11 * 8 + 1 &&
+                                  len_ts == 512 && wl_sch == 11 * 8 + 512 && src.ntaps == 47;
+            // only while every workgroup of the launch is resident at once: a workgroup waiting at a stream barrier holds its
+            // slot, which costs nothing in the latency regime (64 streams: 0.234 vs 0.237 ms per step) and a fifth of the
+            // throughput beyond it (256 streams: 0.73 vs 0.63 ms; 1024: 2.53 vs 2.13)
             // (and only for a call that runs on ONE lane: four lanes of 64 streams each would put 3 072 waiting workgroups on
-            // 768 slots -- measured 0.70 against 0.63 ms at 256 streams)
-            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && lds <= 52 * 1024 &&
-                           (long)H * S <= 3L * c->n_cu && c->n_lanes_used == 1;
+            // 768 slots -- measured 0.70 against 0.63 ms at 256 streams).  The slots per CU come from the occupancy of the
+            // very instantiation and LDS size that would be launched, not from a literal.
+            const int variant = !repl ? 2 : (ref_geom ? 0 : 1);
+            const int per_cu = lds <= 159 * 1024 ? post_chain_blocks_per_cu(c, variant, lds) : 0;
+            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && per_cu > 0 &&
+                           (long)H * S <= (long)per_cu * c->n_cu && c->n_lanes_used == 1;
             if (chain->fused) {
                 const size_t need = (size_t)2 * S * sizeof(unsigned);
                 if (c->cur->postctr.cap < need) {
                     RET_IF(ensure(c, c->cur->postctr, need));
                     HIPCHK(c, hipMemsetAsync(c->cur->postctr.p, 0, c->cur->postctr.cap, c->cur->stream));
                 }
-                const size_t need_x = (size_t)S * 2 * 4 * 2 * H * sizeof(unsigned long long);
-                if (repl && (c->cur->xch.cap < need_x || c->cur->xch_S != S || c->cur->xch_H != H)) {
-                    // a new geometry: every granule EMPTY (all ones), launch counters zero.  (Between launches of one geometry the
-                    // kernel keeps the next launch's half of the block EMPTY itself.)
-                    if (c->capturing) return GSMCAL_E_HIP;      // (cannot happen: a captured call repeats the previous call's geometry)
+                // k_post_chain_r's exchange block [S][2 parities][4 stages][MAXH][2] and launch counters [S]: the layout does
+                // not depend on the batch geometry (fixed MAXH stride per stage, one counter per stream in a buffer of its
+                // own), and every launch leaves the parity it did not use EMPTY for all MAXH windows -- so launches of any
+                // (S, H), eager or replayed from a graph captured here or by the caller, may follow each other.
+                // Only growth re-creates the pair (all granules EMPTY, all counters zero); ensure() bumps ws_epoch then.
+                const size_t need_x = (size_t)S * 2 * 4 * 2 * MAXH * sizeof(unsigned long long), need_e = (size_t)S * sizeof(unsigned);
+                if (repl && (c->cur->xch.cap < need_x || c->cur->xepoch.cap < need_e)) {
+                    if (c->capturing) return GSMCAL_E_HIP;      // (cannot happen: the eager call before a capture sized both)
                     RET_IF(ensure(c, c->cur->xch, need_x));
+                    RET_IF(ensure(c, c->cur->xepoch, need_e));
                     HIPCHK(c, hipMemsetAsync(c->cur->xch.p, 0xFF, c->cur->xch.cap, c->cur->stream));
-                    HIPCHK(c, hipMemsetAsync(c->cur->postctr.p, 0, c->cur->postctr.cap, c->cur->stream));
-                    c->cur->xch_S = S; c->cur->xch_H = H;
+                    HIPCHK(c, hipMemsetAsync(c->cur->xepoch.p, 0, c->cur->xepoch.cap, c->cur->stream));
                 }
                 PostChainArgs pa;
                 memset(&pa, 0, sizeof(pa));
@@ -477,10 +504,8 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.win = win; pa.win_stream_stride = sstride; pa.win_stride = wstride;
                 pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
                 pa.with_totals = chain->table ? 1 : 0;
-                const bool ref_geom = g.ov == 8 && g.nfft == 148 * 8 && g.fine_nshift == 128 * 8 + 1 && g.sch_nshift == 11 * 8 + 1 &&
-                                      len_ts == 512 && wl_sch == 11 * 8 + 512 && src.ntaps == 47;
-                if (repl && ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
-                else if (repl) LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, pa.gen);
+                if (repl && ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, (unsigned*)c->cur->xepoch.p);
+                else if (repl) LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, (unsigned*)c->cur->xepoch.p);
                 else LAUNCH(c, k_post_chain, dim3(H, S), dim3(PC_THREADS), lds, st, pa);
                 CHECK_LAUNCH(c);
                 return 0;
@@ -1006,6 +1031,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (lse) c->lane_stagger = atoi(lse) != 0;
     const char* fpe = getenv("GSMCAL_FUSE_POST");
     if (fpe) c->fuse_post = atoi(fpe) != 0;
+    const char* pse = getenv("GSMCAL_POST_SLOTS");
+    if (pse && atoi(pse) >= 1) c->post_slots_cap = atoi(pse);
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
@@ -1042,7 +1069,7 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
-        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.postctr, &L.xch};
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.postctr, &L.xch, &L.xepoch};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1825,10 +1852,29 @@ int gsmcal_comm_init_file_nonce(gsmcal_ctx* c, const char* path, unsigned long l
     return rc;
 }
 
+// The nonce gsmcal_comm_init_file uses when the caller names none: GSMCAL_COMM_NONCE if set, else a hash of what identifies
+// this LAUNCH to every one of its ranks -- the launcher's run id (torchrun / torch.distributed.run export TORCHELASTIC_RUN_ID),
+// a batch scheduler's job id, or the rendezvous address (MASTER_ADDR:MASTER_PORT) -- so that a record an earlier, crashed
+// bootstrap left at the path is never accepted.  0 only when the environment offers none of these: readers then
+// fall back to the age test (GSMCAL_COMM_STALE_S), which cannot tell a relaunch inside the stale window from this launch.
+static unsigned long long default_launch_nonce() {
+    if (const char* e = getenv("GSMCAL_COMM_NONCE")) return strtoull(e, nullptr, 0);
+    std::string id;
+    for (const char* name : {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID"})
+        if (const char* v = getenv(name)) { if (*v) { id += name; id += '='; id += v; id += ';'; } }
+    const char* ma = getenv("MASTER_ADDR");
+    const char* mp = getenv("MASTER_PORT");
+    if (ma && mp && *ma && *mp) { id += ma; id += ':'; id += mp; }
+    if (id.empty()) return 0;
+    unsigned long long h = 0xcbf29ce484222325ull;           // FNV-1a, 64 bit
+    for (unsigned char ch : id) { h ^= ch; h *= 0x100000001b3ull; }
+    return h ? h : 1;
+}
+
+unsigned long long gsmcal_comm_default_nonce(void) { return default_launch_nonce(); }
+
 int gsmcal_comm_init_file(gsmcal_ctx* c, const char* path, int world, int rank, gsmcal_comm** out) {
-    unsigned long long nonce = 0;
-    if (const char* e = getenv("GSMCAL_COMM_NONCE")) nonce = strtoull(e, nullptr, 0);
-    return gsmcal_comm_init_file_nonce(c, path, nonce, world, rank, out);
+    return gsmcal_comm_init_file_nonce(c, path, default_launch_nonce(), world, rank, out);
 }
 
 void gsmcal_comm_destroy(gsmcal_comm* g) {

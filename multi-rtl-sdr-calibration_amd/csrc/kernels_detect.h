@@ -45,8 +45,13 @@ __device__ __forceinline__ void fft16(cplx* x) {
 
 // SNR from the power spectrum P[0..L) (move_fft_snr_runtime_avg.m:22-27): first max, 3 circular bins
 // around it vs the rest, in dB.  L is a compile-time constant so P stays in registers.
+// floor2 >= 0 (batch path, DecView::floor2): the DC term was removed by linearity, which leaves up to ~2^-46 |mean * sum(coef)|
+// of rounding residue on every sample.  A window whose whole power is below that residue is EXACTLY zero in the reference's
+// arithmetic (it subtracts the mean from the integer samples first: raw2iq.m:8), where 0/0 makes the SNR NaN
+// (move_fft_snr_runtime_avg.m:26-27) -- a constant or zero-filled stretch of a capture; NaN is returned for it here too
+// instead of the ratio of two residues.  floor2 < 0: never (plain arrays, exact operation order).
 template <int L>
-__device__ __forceinline__ double snr_from_power(const double (&P)[L]) {
+__device__ __forceinline__ double snr_from_power(const double (&P)[L], double floor2 = -1.0) {
     // first max (strict >) and its two circular neighbours, carried along in one pass
     double pm = P[L - 1], pc = P[0], pp = P[1 % L];
 #pragma unroll
@@ -62,6 +67,7 @@ __device__ __forceinline__ double snr_from_power(const double (&P)[L]) {
 #pragma unroll
     for (int k = 0; k < L; ++k) tot += P[k];
     const double noise = tot - sig;
+    if (tot <= floor2) return __longlong_as_double(0x7ff8000000000000LL);
     return 10.0 * log10(sig / noise);
 }
 
@@ -75,6 +81,7 @@ struct DecView {
     double mr, mi;      // the mean itself, for the head rows
     const double* head; // head[j] = sum_{k <= min(ntaps-1, decim*j)} coef[k], j < n_head: the rows whose filter()
     int n_head;         // window still overlaps the zero initial state (row 0 only when ntaps <= decim + 1)
+    double floor2;      // power below which a 16-point window is rounding residue of the DC removal (snr_from_power); -1: none
 };
 // DC removal of a sample that was loaded raw
 __device__ __forceinline__ cplx dv_fix(const DecView& v, cplx x, long j) {
@@ -100,7 +107,7 @@ __device__ __forceinline__ double window_snr16_from(const DecView& v, const cplx
     double P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }   // abs(fft(.)).^2
-    return snr_from_power<16>(P);
+    return snr_from_power<16>(P, v.floor2);
 }
 __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     cplx x[16];
@@ -111,7 +118,7 @@ __device__ __forceinline__ double window_snr16(const DecView& v, long start) {
     double P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }   // abs(fft(.)).^2
-    return snr_from_power<16>(P);
+    return snr_from_power<16>(P, v.floor2);
 }
 
 // generic length (2..64) via direct DFT with tw[m] = exp(-2*pi*i*m/L); nothing is stored: the bins
@@ -148,7 +155,7 @@ __device__ __noinline__ double window_snr_generic(const DecView& s, long start, 
 
 // The windows that overlap filter()'s zero initial state (start < n_head; one per stream for the drivers' filters):
 // sample-by-sample DC removal; hx holds the corrected samples of the window.
-__device__ __forceinline__ double window_snr16_head(const cplx* hx) {
+__device__ __forceinline__ double window_snr16_head(const cplx* hx, double floor2) {
     cplx x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = hx[i];
@@ -156,7 +163,7 @@ __device__ __forceinline__ double window_snr16_head(const cplx* hx) {
     double P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const cplx X = x[fft16_rev(k)]; P[k] = X.x * X.x + X.y * X.y; }
-    return snr_from_power<16>(P);
+    return snr_from_power<16>(P, floor2);
 }
 
 __device__ __forceinline__ double window_snr(const DecView& s, long start, int fft_len, const cplx* tw) {
@@ -219,6 +226,8 @@ __device__ __forceinline__ DecView dec_view(const CoarseArgs& a, int stream, dou
     v.mr = mean_re; v.mi = mean_im;
     v.head = a.csum_head;
     v.n_head = a.mean_corr ? a.n_head : 0;
+    // (16 |c| 2^-46)^2: sixteen samples, each within 2^-46 |c| of the value the reference's order of operations gives
+    v.floor2 = a.mean_corr ? 256.0 * (v.cr * v.cr + v.ci * v.ci) * 2.019483917365790e-28 : -1.0;
     return v;
 }
 
@@ -424,7 +433,7 @@ __global__ void __launch_bounds__(SCREEN ? CS_SNR_THREADS : 256) __attribute__((
         const int nh = s.n_head < 8 ? s.n_head : 8;
         if (tid < nh + g.fft_len - 1 && tid < g.n_first) hx[tid] = dv_load(s, tid);
         __syncthreads();
-        if (tid < nh && tid < g.nwin) tab[tid] = window_snr16_head(hx + tid);
+        if (tid < nh && tid < g.nwin) tab[tid] = window_snr16_head(hx + tid, s.floor2);
     }
     DEV_STAMP(KID_COARSE_SNR, blockIdx.y * gridDim.x + blockIdx.x, 1);
 }
@@ -877,6 +886,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                         }
                         if (tid < 64) {
                             const bool cand = lane < nt;
+                            bool residue = false;
                             if (fast) {
                                 if (cand) {                              // candidate `lane` (move_fft_snr_runtime_avg.m:22-27)
                                     double P[16];
@@ -900,11 +910,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                                         for (int k = 0; k < 16; ++k) tot += P[k];
                                         c_sig = sig; c_noise = tot - sig;
                                         v = 10.0 * log10(c_sig / c_noise);
+                                        if (tot <= s.floor2) v = __longlong_as_double(0x7ff8000000000000LL);   // rounding residue of the DC removal: 0/0 in the reference (snr_from_power)
                                     } else {                             // (the tree total differs from the sequential one by ~1e-16: inside eps)
                                         double t8[8];
 #pragma unroll
                                         for (int k = 0; k < 8; ++k) t8[k] = P[2 * k] + P[2 * k + 1];
-                                        c_sig = sig; c_noise = (((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]))) - sig;
+                                        const double tot = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+                                        c_sig = sig; c_noise = tot - sig;
+                                        residue = tot <= s.floor2;       // ... a NaN SNR there: a definite miss
                                     }
                                 }
                             } else if (cand) {
@@ -913,8 +926,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
                             bool is_hit, is_unc;
                             if (ratio_mode) {
                                 const bool okn = c_noise > 0.0 && c_noise < INFINITY && c_sig < INFINITY;
-                                is_hit = cand && okn && c_sig > Rhi * c_noise;
-                                is_unc = cand && !(is_hit || (okn && c_sig < Rlo * c_noise));
+                                is_hit = cand && !residue && okn && c_sig > Rhi * c_noise;
+                                is_unc = cand && !residue && !(is_hit || (okn && c_sig < Rlo * c_noise));
                             } else {
                                 is_hit = cand && (v - hit_avg_snr > th);     // NaN compares false
                                 is_unc = !exact && cand && !(fabs((v - hit_avg_snr) - th) > cert_delta);

@@ -1162,10 +1162,17 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     unsigned char* smem = smem_all + PCR_STATE_BYTES;               // the stages' work area
     StreamState* shv = sh - s;                                      // so that the stage bodies' `sts + blockIdx.y` is the LDS copy
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    // exchange block of stream s: [parity][stage][MAXH][2] -- a layout that does not depend on this launch's H or S, so launches
+    // of any geometry (eager, or replayed from graphs captured at different times) can follow each other on one block
     const unsigned par = epoch[s] & 1u;
-    unsigned long long* mine_x = xch + ((size_t)s * 2 + par) * 4 * 2 * H;        // [stage][w][2]
-    unsigned long long* other_x = xch + ((size_t)s * 2 + (par ^ 1u)) * 4 * 2 * H;
-    if (tid < 8) __hip_atomic_store(other_x + (size_t)(tid >> 1) * 2 * H + 2 * w + (tid & 1), PCR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int XST = 2 * MAXH;                                                // granules per stage
+    unsigned long long* mine_x = xch + ((size_t)s * 2 + par) * 4 * XST;          // [stage][w][2]
+    unsigned long long* other_x = xch + ((size_t)s * 2 + (par ^ 1u)) * 4 * XST;
+    // the parity this launch does not use is left EMPTY for ALL MAXH windows (workgroup w clears w, w+H, w+2H, ...): the next
+    // launch may run more windows per stream than this one
+    if (tid < 8)
+        for (int wq = w; wq < MAXH; wq += H)
+            __hip_atomic_store(other_x + (size_t)(tid >> 1) * XST + 2 * wq + (tid & 1), PCR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         const uint4* src = (const uint4*)(sts + s);
         uint4* dst = (uint4*)sh;
@@ -1197,7 +1204,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 4);
-    pcr_exchange(mine_x + 2 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    pcr_exchange(mine_x + XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);
         if (lane < H && lane < MAXH) {
@@ -1217,7 +1224,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     window_sch_body<(OV > 0 ? 2 : 1)>(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 7);
-    pcr_exchange(mine_x + 4 * H, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    pcr_exchange(mine_x + 2 * XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);
         const bool act = lane < H && lane < MAXH && lane < n_sch_win;
@@ -1236,7 +1243,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 10);
-    pcr_exchange(mine_x + 6 * H, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
+    pcr_exchange(mine_x + 3 * XST, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
     if (w != 0) return;                                             // workgroup 0 finishes the stream
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);

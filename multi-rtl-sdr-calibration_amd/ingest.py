@@ -77,6 +77,13 @@ def read_exact(sock, view, timeout=1.0):
             got += k
     except (socket.timeout, BlockingIOError):
         pass
+    finally:
+        # the socket keeps the configured timeout, not the residue of the last recv: the command packets that follow on the
+        # same connection (set_freq_tcp / set_gain_tcp: sendall) must not inherit a deadline of microseconds
+        try:
+            sock.settimeout(timeout)
+        except OSError:
+            pass
     return got
 
 

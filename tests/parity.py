@@ -58,3 +58,44 @@ def compare_stream(orc, row, det, i, pos_info):
     assert_ppm(row[3], orc["carrier_ppm"][1], "carrier_ppm(2)")
     assert_ppm(row[4], orc["total_sampling_ppm"], "total sampling ppm")
     assert_ppm(row[5], orc["total_carrier_ppm"], "total carrier ppm")
+
+
+# ---- helpers for tests that need many streams: worker functions for a SPAWNED process pool (a pytest process that has
+# already initialised HIP must not fork) --------------------------------------------------------------------------------
+def gen_stream_job(job):
+    """job = (dongle, num_frames, kwargs) -> uint8 capture"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    dongle, frames, kw = job
+    from gsmcal import synth
+    return synth.make_stream(dongle=dongle, num_frames=frames, **kw)[0]
+
+
+def oracle_job(job):
+    """job = (raw, coef, ts, fc) -> oracle.calibrate_stream dict (without the corrected stream)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import gsmcal_oracle as oracle
+    raw, coef, ts, fc = job
+    return oracle.calibrate_stream(raw, coef, ts, fc)
+
+
+def pool_map(fn, jobs, max_workers=32):
+    """fn over jobs on spawned worker processes (safe after the parent initialised the GPU); serial when only one core"""
+    import multiprocessing as mp
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(ncpu, max_workers, len(jobs)))
+    if workers == 1:
+        return [fn(j) for j in jobs]
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(fn, jobs, chunksize=1))

@@ -190,6 +190,29 @@ def test_id_file_bootstrap_ignores_a_stale_file(tmp_path, nonce):
     assert rc < 0
 
 
+def test_default_launch_nonce_comes_from_the_launcher_environment(monkeypatch):
+    """gsmcal_comm_init_file without an explicit nonce must not fall back to "any record younger than 120 s" when
+    the launcher identifies the launch: the nonce is GSMCAL_COMM_NONCE, else a hash of the run / job id and the rendezvous
+    address; two launches differ, the ranks of one launch agree, and only a bare environment gives 0."""
+    import gsmcal
+    lib = gsmcal.load()
+    for k in ("GSMCAL_COMM_NONCE", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert lib.gsmcal_comm_default_nonce() == 0
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    a = lib.gsmcal_comm_default_nonce()
+    assert a != 0 and a == lib.gsmcal_comm_default_nonce()
+    monkeypatch.setenv("MASTER_PORT", "29501")
+    b = lib.gsmcal_comm_default_nonce()
+    assert b not in (0, a)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-7")
+    c = lib.gsmcal_comm_default_nonce()
+    assert c not in (0, a, b)
+    monkeypatch.setenv("GSMCAL_COMM_NONCE", "0x1234")
+    assert lib.gsmcal_comm_default_nonce() == 0x1234
+
+
 def test_plain_bench_gpus_n_starts_its_own_ranks_and_fails_clearly_without_the_devices():
     """`python bench.py --gpus N` (no launcher) must start N ranks itself; on a node with fewer devices
     every rank says so and the command exits non-zero -- after spawning, not on a launcher check."""

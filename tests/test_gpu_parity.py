@@ -489,6 +489,29 @@ def test_large_batches_take_the_throughput_paths(g, setup):
     assert np.array_equal(sc["snr"][3:], np.tile(sc["snr"][:3], 200)[3:])
 
 
+# ---- the BASELINE batch shape itself against the oracle ----------------------------------------------------
+def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setup):
+    """BASELINE config 4 on one GPU as bench.py runs it: 64 DISTINCT streams x 1 020 000 samples -- the first
+    64 seeds of rank 0's range that the chain calibrates (bench.py's selection, so every stream does the full work) -- in ONE
+    calibrate call, and EVERY row against the oracle: positions bit for bit, ppm within 1e-6."""
+    ncand = 64 + 64 // 3 + 8
+    cands = parity.pool_map(parity.gen_stream_job, [(100000 + i, 102, {}) for i in range(ncand)])
+    picked, lo = [], 0
+    while len(picked) < 64:
+        assert lo < len(cands), "bench.py's candidate range no longer holds 64 calibratable seeds"
+        res = g.calibrate_batch(np.stack(cands[lo: lo + 64]), setup["coef"], setup["ts"], FC)
+        picked += [cands[lo + i] for i in range(len(res["table"])) if res["table"][i, 9] == 0]
+        lo += 64
+    raw = np.stack(picked[:64])
+    assert len({r.tobytes()[:4096] for r in raw}) == 64
+    out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    det = g.last_batch_details(64)
+    assert np.all(out["table"][:, 9] == 0)
+    orcs = parity.pool_map(parity.oracle_job, [(raw[i], setup["coef"], setup["ts"], FC) for i in range(64)])
+    for i in range(64):
+        parity.compare_stream(orcs[i], out["table"][i], det, i, out["pos_info"][i])
+
+
 # ---- full BASELINE size: size-independent properties ---------------------------------------------------
 def test_full_size_batch_properties(g, setup):
     """64 streams x 1 020 000 samples (BASELINE config 4 on one GPU): (1) every stream's row equals the

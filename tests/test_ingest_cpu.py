@@ -140,6 +140,9 @@ def test_read_timeout_bounds_the_whole_read_and_pairing_survives_an_odd_short_re
         stop.set()
         t.join(2.0)
         assert 0 < got < 1000 and dt < 1.0, (got, dt)     # round 2: every recv re-armed the timeout and this took 50 s
+        # the socket leaves read_exact with the CONFIGURED timeout, not the residue of its last recv (the command
+        # packets that follow on the same connection would inherit a deadline of microseconds)
+        assert a.gettimeout() == pytest.approx(0.4)
     finally:
         a.close(); b.close()
 
