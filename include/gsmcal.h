@@ -276,6 +276,18 @@ void gsmcal_comm_destroy(gsmcal_comm* comm);
 int gsmcal_allgather_table(gsmcal_ctx* ctx, gsmcal_comm* comm, const double* d_local, int rows_per_rank, int cols,
                            double* d_all);
 
+/* The same collective off the critical path of the caller's stream: RCCL runs on a side stream of the context, behind an event
+ * recorded on the context's stream at the time of the call; the context's stream does NOT wait for it, so the kernels of the
+ * next batch start at once and the gather of batch i travels under the kernels of batch i+1 (gsm_sync_demod.m:151-158 only
+ * needs the gathered table after the per-dongle loop).  `slot` (0..3) names the buffer pair in flight:
+ *   gsmcal_allgather_wait(ctx, slot)  the context's stream waits -- on the GPU -- for that slot's collective: call it before
+ *                                     enqueueing whatever overwrites d_local or reads d_all of the slot (no-op for a slot never posted);
+ *   gsmcal_allgather_sync(ctx, slot)  blocks the host until that slot's collective has finished. */
+int gsmcal_allgather_table_async(gsmcal_ctx* ctx, gsmcal_comm* comm, const double* d_local, int rows_per_rank, int cols,
+                                 double* d_all, int slot);
+int gsmcal_allgather_wait(gsmcal_ctx* ctx, int slot);
+int gsmcal_allgather_sync(gsmcal_ctx* ctx, int slot);
+
 /* ---- ingest ring: rtl_tcp bytes -> pinned host ring -> asynchronous H2D ----------------------------------
  * The reference reads every capture with fread(tcp_obj, 2*num_sample, 'uint8') into MATLAB memory and processes it in
  * place (gsm_sync_demod.m:94-104, multi_rtl_sdr_gsm_FCCH_scanner.m:117-131).  Here the socket reader writes straight into

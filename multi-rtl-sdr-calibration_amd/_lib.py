@@ -78,6 +78,9 @@ SIGNATURES = {
     "gsmcal_comm_id_file_remove": (C.c_int, [C.c_char_p]),
     "gsmcal_comm_destroy": (None, [C.c_void_p]),
     "gsmcal_allgather_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gsmcal_allgather_table_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "gsmcal_allgather_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "gsmcal_allgather_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmcal_ring_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmcal_ring_destroy": (None, [C.c_void_p]),
     "gsmcal_ring_host": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -117,6 +117,11 @@ struct gsmcal_ctx {
     int tw_n = 0;                            // length the twiddle table was built for
     std::vector<double> h_coef, h_ts, h_cf;   // host copies: upload only when changed
     int last_S = 0;
+    // gsmcal_allgather_table_async: the collective on a side stream, behind / ahead of events on the context's stream
+    static constexpr int AG_SLOTS = 4;
+    hipStream_t ag_stream = nullptr;
+    hipEvent_t ag_ready[AG_SLOTS] = {nullptr, nullptr, nullptr, nullptr}, ag_done[AG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool ag_posted[AG_SLOTS] = {false, false, false, false};
     // profiling
     bool prof = false;
     std::string prof_filter;
@@ -1077,6 +1082,12 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->ag_stream) (void)hipStreamSynchronize(c->ag_stream);
+    for (int i = 0; i < gsmcal_ctx::AG_SLOTS; ++i) {
+        if (c->ag_ready[i]) (void)hipEventDestroy(c->ag_ready[i]);
+        if (c->ag_done[i]) (void)hipEventDestroy(c->ag_done[i]);
+    }
+    if (c->ag_stream) (void)hipStreamDestroy(c->ag_stream);
     for (int i = 0; i < gsmcal_ctx::GRAPH_SLOTS; ++i)
         for (auto* g : {&c->g_calib[i], &c->g_scan[i]}) {
             if (g->exec) (void)hipGraphExecDestroy(g->exec);
@@ -1894,6 +1905,57 @@ int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local,
         c->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
         return GSMCAL_E_HIP;
     }
+    return 0;
+}
+
+// The same collective OFF the chain's critical path: RCCL runs on a side stream of the context, ordered
+// behind an event recorded on the context's stream now; the context's stream itself does not wait, so the next batch's
+// kernels start at once and the gather of batch i travels under the kernels of batch i+1.
+int gsmcal_allgather_table_async(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local, int rows_per_rank, int cols, double* d_all, int slot) {
+    if (!c || !g || !d_local || !d_all || rows_per_rank < 1 || cols < 1 || slot < 0 || slot >= gsmcal_ctx::AG_SLOTS) return GSMCAL_E_ARG;
+    RcclApi* a = rccl_api();
+    if (!a) return GSMCAL_E_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ag_stream) {
+        int lo = 0, hi = 0;                                     // lowest priority: the collective never delays the chain's kernels
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->ag_stream, hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(c, hipStreamCreateWithFlags(&c->ag_stream, hipStreamNonBlocking));
+        }
+    }
+    if (!c->ag_ready[slot]) {
+        // device-scope release: the table only has to be visible to the collective's kernel on this device; a default event
+        // flushes to system scope at every record (see get_event())
+        unsigned fl = hipEventDisableTiming | hipEventReleaseToDevice;
+        if (const char* e = getenv("GSMCAL_AG_EVENT_FLAGS")) fl = (unsigned)strtoul(e, nullptr, 0);
+        if (hipEventCreateWithFlags(&c->ag_ready[slot], fl) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(c, hipEventCreateWithFlags(&c->ag_ready[slot], hipEventDisableTiming));
+        }
+    }
+    if (!c->ag_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ag_done[slot], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ag_ready[slot], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->ag_stream, c->ag_ready[slot], 0));
+    const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, c->ag_stream);
+    if (r != ncclSuccess) {
+        c->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
+        return GSMCAL_E_HIP;
+    }
+    HIPCHK(c, hipEventRecord(c->ag_done[slot], c->ag_stream));
+    c->ag_posted[slot] = true;
+    return 0;
+}
+
+int gsmcal_allgather_wait(gsmcal_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= gsmcal_ctx::AG_SLOTS) return GSMCAL_E_ARG;
+    if (c->ag_posted[slot]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ag_done[slot], 0));
+    return 0;
+}
+
+int gsmcal_allgather_sync(gsmcal_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= gsmcal_ctx::AG_SLOTS) return GSMCAL_E_ARG;
+    if (c->ag_posted[slot]) HIPCHK(c, hipEventSynchronize(c->ag_done[slot]));
     return 0;
 }
 
