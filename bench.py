@@ -33,7 +33,61 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # HBM bytes per launch from committed rocprofv3 --pmc passes
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (dense; the matrix pipe has the same fp64 peak)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0    # wave-level VALU instructions per second: one per SIMD every 4 cycles, whatever the type
+
+
+def _newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return c[-1] if c else os.path.join(ROOT, "profiles", "r03_" + suffix)
+
+
+PMC_FILE = _newest_profile("pmc_traffic.json")      # HBM bytes per launch from committed rocprofv3 --pmc passes
+VALU_FILE = _newest_profile("valu_per_step.json")   # wave-level VALU instructions per step from committed SQ passes
+
+
+def useful_flop_per_stream(n_samples, ntaps, n_windows=10, mode="table"):
+    """Useful fp64 floating-point operations of ONE stream through the chain: the arithmetic the algorithm as implemented needs
+    (a complex MAC = 8, a real-coefficient complex MAC = 4 flop), without address arithmetic, conversions, reductions' shuffles or
+    anything re-computed for convenience.  Itemised so that DESIGN.md can be checked against it."""
+    nd = (n_samples + 63) // 64
+    f = {}
+    f["front_fir_kept_rows"] = nd * ntaps * 4                                   # filter() at the rows r(1:64:end) only
+    f["coarse_window_spectra"] = (3594 - 15) * (5 * 16 * 4 + 16 * 3 + 40)         # 16-point FFT + powers + SNR per moving-search window
+    f["fine_window_build"] = n_windows * 2208 * ntaps * 4                       # filter() on the 2208 samples of each fine window
+    f["fine_certificate"] = n_windows * (8 * 2208 * 8 + 16 * 8 * 37 * 8 + 8 * 1024 * 11 + 2208 * 6 + 1025 * 12)   # level-1 sums, anchors, slides, E(t), bounds
+    per_burst = 1184 * 6 + 7 * 1184 * 8 + 1184 * 40                             # lerp, 7 candidate bins, unit-phasor step
+    gate = 19 * 32 * 18 * 4 + 110 * 32 * 8 + 1184 * 16                          # rotation + 37 x 32 transform on the gate's 110 bins
+    f["burst_estimates"] = n_windows * (2 * per_burst + gate + 1184 * 14)       # FCCH_fine_correction + carrier_correct_post_SCH bursts (+ the level-2/3 chain of the second)
+    f["sch_correlation"] = n_windows * (600 * ntaps * 4 + 600 * 20 + 89 * 512 * 8)   # window through the chain + 89 x 512 complex MACs
+    if mode == "stream":
+        f["corrected_stream"] = n_samples * (ntaps * 4 + 2 * (6 + 8))           # filter() at every sample + two lerps + two derotations
+    return f
+
+
+def compute_roofline(regime, streams, n_samples, ntaps, seconds_per_step, mode="table"):
+    """The compute side of the roofline for one regime of the chain: useful fp64 FLOP per step against the
+    78.6 TFLOP/s vector peak, and VALU issue utilisation = wave-level VALU instructions per step (committed SQ pass) over
+    what the 1024 SIMDs can issue in the measured step time."""
+    items = useful_flop_per_stream(n_samples, ntaps, mode=mode)
+    flop = float(sum(items.values())) * streams
+    out = {"useful_fp64_flop": int(flop), "achieved_TFLOPs": round(flop / seconds_per_step / 1e12, 3),
+           "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "frac_of_78.6TF": round(flop / seconds_per_step / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4),
+           "valu_issue_util": None}
+    try:
+        with open(VALU_FILE) as fh:
+            v = json.load(fh).get(regime)
+        if v:
+            n = float(v["valu_wave_instr_per_step"])
+            out["valu_wave_instr_per_step"] = int(n)
+            out["valu_issue_util"] = round(n / VALU_ISSUE_PEAK / seconds_per_step, 4)
+            out["valu_per_useful_flop_lane"] = round(n * 64 / flop, 3)
+            out["valu_source"] = os.path.relpath(VALU_FILE, ROOT) + " (committed rocprofv3 SQ pass of this configuration; not measured in this run)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def parse():
@@ -301,7 +355,16 @@ def main():
     # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
     # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written, and the only wait is
     # before a buffer is written again two steps later (gsmcal.dist.TableGatherer; uneven shards are padded).
-    tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev) if use_dist else None
+    # N > 1: the C ABI's own all-gather, in line on the chain's stream (GSMCAL_BENCH_GATHER=async: on the library's side stream;
+    # =torch: torch.distributed's collective, round 3's path) -- tools/dist_cost.py has what each costs per step on one rank
+    tg, gather_kind, ncomm = None, "none", None
+    if use_dist:
+        gather_kind = os.environ.get("GSMCAL_BENCH_GATHER", "native")
+        if gather_kind == "torch":
+            tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
+        else:
+            ncomm = gdist.native_comm_from_process_group(ctx, dev)
+            tg = gdist.NativeTableGatherer(ctx, ncomm, sizes, gsmcal.TABLE_COLS, dev, mode="async" if gather_kind == "async" else "inline")
     host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
 
@@ -384,7 +447,9 @@ def main():
                                f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation, table on the host",
                    "streams_per_gpu": Dmax, "streams_total": sum(sizes), "samples_per_stream": N, "output": args.mode,
                    "bytes_per_sample_algorithmic": bps,
-                   "collective": "all_gather(table) over RCCL" if use_dist else "none",
+                   "collective": {"none": "none", "native": "all_gather(table): gsmcal_allgather_table (native RCCL) in line on the chain's stream",
+                                  "async": "all_gather(table): gsmcal_allgather_table_async (native RCCL on a side stream)",
+                                  "torch": "all_gather(table): torch.distributed over RCCL"}.get(gather_kind, gather_kind),
                    "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked,
                    "gathered_table_checked_against_every_rank": gathered_ok},
     }
@@ -420,6 +485,7 @@ def main():
                 roof["time_dominant_kernel"] = {"name": dom, "ms_per_step": round(tot[dom] / args.steps, 4),
                                                 "bound": "latency (serial fp64 dependency chains, one to three workgroups per CU)"}
         out["roofline"] = roof
+        out["roofline_compute"] = compute_roofline("calib_64" if Dmax == 64 else f"calib_{Dmax}", Dmax, N, len(coef), elapsed / args.steps, args.mode)
         if world == 1 and not args.no_sub:
             out["sub_results"] = sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mixed_raw, distinct)
         # ---- CPU baseline: the oracle (fp64 NumPy/SciPy restatement) on the host cores, bounded sample ----
@@ -459,6 +525,9 @@ def main():
             out["parity_checked_streams"] = n_rank_checked
         print(json.dumps(out))
     if use_dist:
+        if ncomm is not None:
+            torch.cuda.synchronize(dev)
+            ncomm.close()
         dist.destroy_process_group()
 
 
@@ -488,7 +557,7 @@ def pmc_traffic(kernel, D, N):
         return None, "committed PMC pass is for another batch shape"
     for k, v in pmc.get("hbm_bytes_per_launch", {}).items():
         if k.startswith(kernel[:12]):
-            return v, "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+            return v, os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
     return None, "kernel not in the committed PMC pass"
 
 
@@ -572,7 +641,8 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
             ref = cal.table(0).numpy()
             same = all(np.array_equal(tab[k * cal.D: (k + 1) * cal.D], ref[: len(tab[k * cal.D: (k + 1) * cal.D])], equal_nan=True) for k in range(reps))
             sub["streams_1024"] = {"streams": 1024, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
-                                   "tables_identical_to_headline": bool(same)}
+                                   "tables_identical_to_headline": bool(same),
+                                   "roofline_compute": compute_roofline("calib_1024", 1024, N, len(coef), t)}
             if not args.no_kernel_events:
                 prof = event_pass(ctx, lambda: c2.launch(0), 5, torch, dev)
                 sub["streams_1024"]["kernels_ms_per_step_untimed_pass"] = {k: round(v_[0] / 5, 4) for k, v_ in sorted(prof.items(), key=lambda kv: -kv[1][0])}
@@ -602,7 +672,8 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         v = cal.D * N / t / 1e6
         sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
                               "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
-                              "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4)}
+                              "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4),
+                              "roofline_compute": compute_roofline("stream_mode_64", cal.D, N, len(coef), t, mode="stream")}
         torch.cuda.synchronize(dev)
         assert torch.equal(cs.table(0), cal.table(0)) or bool(torch.allclose(cs.table(0), cal.table(0), equal_nan=True))
         del cs
@@ -620,6 +691,14 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         except Exception as e:  # noqa: BLE001 - a sub-result must not take the headline down
             sub[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
+    # the N > 1 code path on this one GPU: the same K steps in a self-launched child (one rank, RCCL communicator of size 1,
+    # table in device memory + the all-gather + the gathered-table digest check) -- what the collective costs a step
+    # before the first xGMI byte moves
+    if args.mode == "table":
+        try:
+            sub["single_rank_collective"] = bench_single_rank_collective(args, cal.D)
+        except Exception as e:  # noqa: BLE001
+            sub["single_rank_collective"] = {"error": repr(e)}
     # two batches in flight: two contexts on two HIP streams, consecutive steps alternate between them.  Every kernel of
     # the chain at this batch size is latency-bound and leaves most of the GPU idle, so a second, independent batch
     # overlaps almost freely -- the throughput a double-buffered deployment sees.  NOT the headline `value` (that is
@@ -634,6 +713,26 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
     except Exception as e:  # noqa: BLE001
         sub["ingest_ring"] = {"error": repr(e)}
     return sub
+
+
+def bench_single_rank_collective(args, D):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSMCAL_FORCE_DIST"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--streams", str(D), "--frames", str(args.frames), "--distinct", str(args.distinct),
+           "--no-sub", "--no-cpu-baseline", "--no-kernel-events"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if p.returncode != 0 or not line:
+        return {"error": f"child exited {p.returncode}", "stderr_tail": p.stderr[-600:]}
+    r = json.loads(line[-1])
+    return {"streams": D, "ms_per_step": r["ms_per_step"], "Msample_per_s": r["value"], "steps": r["steps"],
+            "collective": r["config"]["collective"],
+            "gathered_table_checked_against_every_rank": r["config"]["gathered_table_checked_against_every_rank"],
+            "rows_checked_vs_oracle": r["config"]["rows_checked_vs_oracle_per_rank"],
+            "what": "GSMCAL_FORCE_DIST=1 python bench.py --gpus 1 as a child process: one rank under torch.distributed.run, table in "
+                    "device memory, one all-gather per step, digest check of the gathered table"}
 
 
 def bench_two_in_flight(args, torch, gsmcal, dev, cal, coef, ts, fc, N):

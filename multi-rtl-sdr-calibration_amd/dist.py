@@ -129,6 +129,74 @@ class NativeComm:
             self.h = None
 
 
+class NativeTableGatherer:
+    """TableGatherer's interface on the C ABI's own collective (gsmcal_allgather_table: native RCCL enqueued by the library,
+    no torch.distributed call per step).  mode "inline": the all-gather sits on the context's stream right behind the kernels
+    that fill the table (one C call, no event traffic between streams -- measured +2 us per 64-stream step on one rank,
+    against +15 us for torch's collective or for any cross-stream event choreography); mode "async":
+    gsmcal_allgather_table_async -- the collective on the library's side stream behind an event, the gather of step i under
+    the kernels of step i+1, at the price of that event (+14 us per step, tools/dist_cost.py)."""
+
+    def __init__(self, ctx, comm, sizes, cols, device, mode="inline", dtype=None):
+        import torch
+        self.ctx, self.comm, self.mode = ctx, comm, mode
+        self.sizes = list(sizes)
+        self.world, self.rank = len(self.sizes), comm.rank
+        self.mx = max(self.sizes)
+        self.cols = int(cols)
+        dtype = dtype or torch.float64
+        self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+
+    def post(self, b, local):
+        import ctypes as C
+        if local.shape[0] != self.sizes[self.rank]:
+            raise ValueError("local table does not match this rank's shard")
+        self.wait(b)
+        src = local
+        if local.shape[0] != self.mx or not local.is_contiguous():     # uneven shards: pad to the largest (NaN rows are dropped by rows())
+            self.send[b][: local.shape[0]].copy_(local)
+            src = self.send[b]
+        if self.mode == "async":
+            self.ctx.check(self.ctx.lib.gsmcal_allgather_table_async(self.ctx.h, self.comm.h, C.c_void_p(src.data_ptr()), self.mx, self.cols,
+                                                                     C.c_void_p(self.recv[b].data_ptr()), b), "gsmcal_allgather_table_async")
+        else:
+            self.comm.allgather_table(src.data_ptr(), self.mx, self.cols, self.recv[b].data_ptr())
+        self.work[b] = True
+
+    def wait(self, b):
+        """the context's stream is ordered behind buffer pair b's collective (a GPU-side wait; stream order alone when inline)"""
+        if self.work[b] is not None and self.mode == "async":
+            self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
+        self.work[b] = None
+
+    def rows(self, b):
+        import torch
+        if self.work[b] is not None and self.mode == "async":
+            self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
+        if all(s == self.mx for s in self.sizes):
+            return self.recv[b]
+        return torch.cat([self.recv[b][r * self.mx: r * self.mx + self.sizes[r]] for r in range(self.world)], dim=0)
+
+    def own_rows(self, b):
+        off = self.rank * self.mx
+        return self.recv[b][off: off + self.sizes[self.rank]]
+
+
+def native_comm_from_process_group(ctx, device, group=None):
+    """A NativeComm spanning the ranks of a torch.distributed process group: rank 0 draws the RCCL id, the group broadcasts it
+    (the one use of torch.distributed in the bootstrap), every rank joins with ncclCommInitRank through the C ABI."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    idt = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(NativeComm.unique_id(ctx)), dtype=torch.uint8))
+    dist.broadcast(idt, 0, group=group)
+    return NativeComm(ctx, world, rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
+
+
 def sampling_phase_difference(pos_info_a, pos_info_b):
     """gsm_sync_demod.m:151-158: per-burst start difference between two dongles' pos_info (8x units)."""
     a = np.atleast_2d(np.asarray(pos_info_a, dtype=np.float64))
