@@ -102,6 +102,7 @@ struct gsmcal_ctx {
     bool post_repl = true;          // GSMCAL_POST_REPL=0: k_post_chain (last arriver decides, state through memory) instead of k_post_chain_r
     bool lane_stagger = false;      // GSMCAL_LANE_STAGGER=1: calibration lanes start one front kernel apart instead of together
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
+    bool stream_s47 = true;         // GSMCAL_STREAM_S47=0: the general k_stream_tile also for the 47-tap symmetric filter
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     struct OccEntry { int variant; size_t lds; int blocks; };
@@ -1040,6 +1041,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (pse && atoi(pse) >= 1) c->post_slots_cap = atoi(pse);
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
+    const char* s47 = getenv("GSMCAL_STREAM_S47");
+    if (s47) c->stream_s47 = atoi(s47) != 0;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
     if (fg && atoi(fg) != 0) c->front_generic = true;
     const char* ge = getenv("GSMCAL_GRAPH");
@@ -1677,7 +1680,12 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             ta.raw = raw_i; ta.raw_stride = 2 * n; ta.coef = (const double*)c->coef.p; ta.ntaps = ntaps;
             ta.dst = (cplx*)d_r_correct + (size_t)lo * n; ta.dst_stream_stride = n;
             const size_t tlds = stream_tile_lds(ntaps);
-            if (tlds <= 64 * 1024) {
+            bool sym = (int)c->h_coef.size() == ntaps;         // exactly mirrored taps (what fir1 returns)
+            for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
+            if (ntaps == 47 && sym && c->stream_s47) {          // the drivers' filter: taps in registers, every sample read once
+                LAUNCH(c, k_stream_tile_s47<ST47_TILE>, dim3((unsigned)((n + (long)ST47_TILE * ST_TPB - 1) / ((long)ST47_TILE * ST_TPB)), S), dim3(ST_THREADS), stream_tile_s47_lds(), (const StreamState*)L.state.p, ta);
+                CHECK_LAUNCH(c);
+            } else if (tlds <= 64 * 1024) {
                 LAUNCH_GEOM(ta.ntaps == 47, c, (k_stream_tile<47>), (k_stream_tile<0>), dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
                 CHECK_LAUNCH(c);
             } else {                                        // very long filters: the general tile gather

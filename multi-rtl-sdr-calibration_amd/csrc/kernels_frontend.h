@@ -943,10 +943,11 @@ __device__ __forceinline__ cplx st_rot(const cplx* T, int sidx, int m) {     // 
 }
 
 struct StRange { long lo0, hi0, lo2, hi2, lo3; int L4, cnt0, cnt2; };
+template <int TILE = ST_TILE>
 __device__ __forceinline__ StRange st_range(long tile, long nq, long n0, long n2, double f1, double f3) {
     StRange r;
-    r.lo3 = tile * ST_TILE;
-    r.L4 = (int)(nq - r.lo3 < ST_TILE ? nq - r.lo3 : ST_TILE);
+    r.lo3 = tile * TILE;
+    r.L4 = (int)(nq - r.lo3 < TILE ? nq - r.lo3 : TILE);
     const long hi3 = r.lo3 + r.L4 - 1;
     r.lo2 = (long)floor((double)r.lo3 * f3);
     r.hi2 = (long)floor((double)hi3 * f3) + 1;
@@ -1145,6 +1146,238 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
         }
         __syncthreads();                                        // buf1 (= xs) and the tables' S slot may be rewritten
         rg = nx; first = nfirst; first_al = nfirst_al; sidx ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stream_tile_s47: k_stream_tile for the drivers' filter -- 47 exactly symmetric taps (fir1(46), gsm_sync_demod.m:34) -- with
+// the two things the general kernel spends most of its LDS bandwidth on removed (round 4; the general kernel's FIR loop issued 24
+// LDS reads per output sample, a third of them tap broadcasts, and the counters put the LDS pipe ahead of the VALU there):
+//   * the 24 distinct taps live in registers (uniform loads, once per workgroup), and the FIR of a lane's four outputs is one
+//     unrolled pass over its 50 input samples, each read ONCE (12.5 LDS reads per output sample) and used at once by the up to
+//     four outputs it belongs to -- every output still takes its taps oldest first, so the sums are those of k_stream_tile
+//     (and of gather_core) bit for bit;
+//   * raw bytes go from the prefetched 16-byte chunk in registers straight to the padded complex copy (no raw-byte staging
+//     area, no ds_read_u16 per sample, no per-sample 64-bit index tests inside the stream).
+// Passes 2 and 3 (lerp x rotator) are k_stream_tile's.  grid (ceil(N / (ST_TILE * ST_TPB)), S), block 256.
+// ------------------------------------------------------------------------------------------------
+// TILE: level-4 samples per tile; TILE + 8 level-0 samples are filtered per tile (the two lerps stretch a tile by < 8).  1016
+// (one FIR round of 256 x 4, 42.5 KB of LDS: three workgroups per CU) or 952 (240 x 4, 40 KB: four per CU)
+#ifndef ST47_TILE
+#define ST47_TILE 952
+#endif
+__host__ __device__ constexpr size_t st47_xs_n(int tile) { return (size_t)(tile + 8 + 47 + 16) + (size_t)(tile + 8 + 47 + 16) / 4 + 2; }
+__host__ __device__ constexpr size_t st47_buf_n(int tile) { return (size_t)tile + 8 + 4; }
+__host__ __device__ inline size_t stream_tile_s47_lds(int tile = ST47_TILE) {
+    const size_t xs_n = st47_xs_n(tile), buf = st47_buf_n(tile);
+    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + 2 * (68 + 34) * sizeof(cplx);
+}
+// four consecutive outputs i0 .. i0+3 (i0 a multiple of 4) of the 47-tap symmetric filter from the padded copy xq; c[t] = coef[t], t < 24
+template <int S0, int G>
+__device__ __forceinline__ void fir4_sym47_load(const cplx* __restrict__ x0, cplx (&v)[G]) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) { constexpr int dummy = 0; (void)dummy; const int sn = S0 + u; v[u] = x0[sn + (sn >> 2)]; }
+}
+template <int S0, int G>
+__device__ __forceinline__ void fir4_sym47_mac(const cplx (&v)[G], const double (&c)[24], double (&ar)[4], double (&ai)[4]) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const int s = S0 + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = s - j;                          // output i0+j takes sample i0+s with tap rev[t] = coef[46-t] = coef[t]
+            if (t >= 0 && t < 47) {
+                const double cc = c[t < 24 ? t : 46 - t];
+                ar[j] = fma(cc, v[u].x, ar[j]);
+                ai[j] = fma(cc, v[u].y, ai[j]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void fir4_sym47(const cplx* __restrict__ xq, const double (&c)[24], int i0, cplx* y) {
+    double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
+    const cplx* x0 = xq + xs_pad(i0);                    // i0 % 4 == 0: xs_pad(i0 + s) = xs_pad(i0) + s + (s >> 2)
+    // ten groups of five samples in two register sets: the next group's LDS reads are issued ahead of this group's FMAs, and a
+    // scheduling barrier per group keeps the compiler from hoisting all fifty reads to the top (255 registers, one wave per SIMD)
+    constexpr int G = 5;
+    cplx A[G], B[G];
+    fir4_sym47_load<0, G>(x0, A);
+#define FIR47_PAIR(g)                                                   \
+    fir4_sym47_load<G * ((g) + 1), G>(x0, B);                           \
+    fir4_sym47_mac<G * (g), G>(A, c, ar, ai);                           \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    if ((g) + 2 < 50 / G) fir4_sym47_load<G * ((g) + 2), G>(x0, A);     \
+    fir4_sym47_mac<G * ((g) + 1), G>(B, c, ar, ai);                     \
+    __builtin_amdgcn_sched_barrier(0);
+    FIR47_PAIR(0) FIR47_PAIR(2) FIR47_PAIR(4) FIR47_PAIR(6) FIR47_PAIR(8)
+#undef FIR47_PAIR
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = make_double2(ar[j], ai[j]);
+}
+
+// what a tile needs to know about itself: worked out ONCE per workgroup for its ST_TPB tiles, one tile per lane, and read back
+// from LDS -- the ranges are floors of double products and 64-bit index arithmetic, which every lane of every wave would
+// otherwise repeat for every tile (no scalar floating-point unit: ~230 vector instructions per wave and tile, a quarter of
+// this kernel's instructions), and the two accurate sincos per tile cost the wave that holds their lanes another ~200
+struct StTile { long lo0, lo2, lo3, first, first_al; int cnt0, cnt2, L4, nchunk; };
+template <int TILE>
+__global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(3, 4))) k_stream_tile_s47(const StreamState* __restrict__ sts, StreamTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ StTile tl[ST_TPB];
+    __shared__ cplx S2[ST_TPB], S4[ST_TPB];                     // exp(1i*fl(k0*c)) per tile and derotation
+    constexpr int ntp = 47;
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const StreamState* st = sts + s;
+    const long n0 = st->n0;
+    const double mr = st->mean_re, mi = st->mean_im;
+    int ty[NLEVELS]; double pa[NLEVELS]; long ln[NLEVELS];
+    ty[0] = OP_NONE; pa[0] = 0.0; ln[0] = n0;
+#pragma unroll
+    for (int j = 1; j < NLEVELS; ++j) { ty[j] = st->op[j].type; pa[j] = st->op[j].param; ln[j] = st->op[j].n; }
+    if (ty[1] != OP_LERP || ty[2] != OP_MIX || (ty[3] != OP_LERP && ty[3] != OP_COPY) || ty[4] != OP_MIX) return;
+    const double f1 = pa[1], c2 = pa[2], f3 = ty[3] == OP_COPY ? 1.0 : pa[3], c4 = pa[4];
+    const long nq = ln[4];
+    const long ntile = (nq + TILE - 1) / TILE;
+    const long tile0 = (long)blockIdx.x * ST_TPB;
+    if (tile0 >= ntile) return;
+    const int ntl = (int)(tile0 + ST_TPB < ntile ? ST_TPB : ntile - tile0);
+    // ---- LDS carve: buf0 | region1 = xs / buf1 | rotator tables ----
+    constexpr size_t xs_n = st47_xs_n(TILE), bufn = st47_buf_n(TILE);
+    cplx* buf0 = (cplx*)smem;
+    cplx* buf1 = buf0 + bufn;
+    cplx* xs = buf1;
+    cplx* T2 = buf1 + (xs_n > bufn ? xs_n : bufn);              // T[2..35] = A[0..33], T[36..67] = B[0..31] (k_stream_tile's layout)
+    cplx* T4 = T2 + 68;
+    cplx* SA2 = T4 + 68;
+    cplx* SA4 = SA2 + 34;
+    const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
+    double cf[24];                                              // the taps (uniform addresses: scalar loads)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) cf[k] = a.coef[k];
+    // ---- once per workgroup: the tiles' ranges (lanes 0..), their S rotators (lanes 32..), the stream's A/B tables (lanes 64..) ----
+    if (tid < ST_TPB) {
+        if (tid < ntl) {
+            const StRange r = st_range<TILE>(tile0 + tid, nq, n0, ln[2], f1, f3);
+            const long ao = (long)(((uintptr_t)base >> 1) & 7);  // samples past a 16-byte boundary at g = 0
+            StTile t;
+            t.lo0 = r.lo0; t.lo2 = r.lo2; t.lo3 = r.lo3; t.cnt0 = r.cnt0; t.cnt2 = r.cnt2; t.L4 = r.L4;
+            t.first = r.lo0 - (ntp - 1);
+            long m = (t.first + ao) % 8;
+            if (m < 0) m += 8;
+            t.first_al = t.first - m;
+            t.nchunk = (int)((t.first + r.cnt0 + ntp - 1 - t.first_al + 7) >> 3);
+            tl[tid] = t;
+        }
+    } else if (tid >= 32 && tid < 32 + 2 * ST_TPB) {
+        const int t = (tid - 32) % ST_TPB, which = (tid - 32) / ST_TPB;
+        if (t < ntl) {
+            const StRange r = st_range<TILE>(tile0 + t, nq, n0, ln[2], f1, f3);
+            double sn, cs;
+            sincos_large(which ? (double)r.lo3 * c4 : (double)r.lo2 * c2, &sn, &cs);
+            (which ? S4 : S2)[t] = make_double2(cs, sn);
+        }
+    } else if (tid >= 64 && tid < 64 + 2 * 66) {
+        const int i = (tid - 64) % 66, which = (tid - 64) / 66;
+        const double c = which ? c4 : c2;
+        double sn, cs;
+        sincos_large(i < 34 ? (double)(32 * i) * c : (double)(i - 34) * c, &sn, &cs);
+        (which ? T4 : T2)[2 + i] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    // B[m] of a lane's samples: i = tid + 256 k, so i & 31 = tid & 31 for every k -- one read per workgroup instead of one per sample
+    const cplx b2 = T2[36 + (tid & 31)], b4 = T4[36 + (tid & 31)];
+    // the first tile's raw bytes: chunk `tid` (8 samples, 16-byte aligned) of [first_al, first + span)
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < tl[0].nchunk) pre = ffast_chunk(base, tl[0].first_al + 8L * tid, n0);
+    for (int t = 0; t < ntl; ++t) {
+        const StTile c = tl[t];
+        const int cnt0 = c.cnt0, cnt2 = c.cnt2, L4 = c.L4;
+        const long lo0 = c.lo0, lo2 = c.lo2, lo3 = c.lo3, first = c.first;
+        {   // raw2iq.m:6-8 from the registers: staged sample i = 8*tid + u - (first - first_al); zeros outside the span / the stream
+            const int span = cnt0 + ntp - 1, off = (int)(first - c.first_al);
+            const int nconv = (off + span + 8 + 7) >> 3;        // (finite zeros behind the span: the last lanes' discarded outputs read them)
+            if (tid < nconv) {
+                const int i_base = 8 * tid - off;
+                const long g_base = first + i_base;
+                const unsigned wv[4] = {pre.x, pre.y, pre.z, pre.w};
+                if (i_base >= 0 && i_base + 8 <= span && g_base >= 0 && g_base + 8 <= n0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned q = wv[u >> 1] >> (16 * (u & 1));
+                        xs[xs_pad(i_base + u)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i_base + u;
+                        const long g = first + i;
+                        const unsigned q = (wv[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+                        cplx v = make_double2(0.0, 0.0);
+                        if (i < span && g >= 0 && g < n0) v = make_double2((double)(q & 0xFF) - mr, (double)(q >> 8) - mi);
+                        if (i >= 0) xs[xs_pad(i)] = v;
+                    }
+                }
+            }
+        }
+        // S * A[q] of this tile for both derotations (34 + 34 products): a sample's rotator is then one product, SA[m>>5]*B[m&31] --
+        // the same three factors as st_rot(), associated the same way ((S*A)*B), bit-identical
+        if (tid >= 128 && tid < 128 + 68) {
+            const int q = (tid - 128) % 34, which = (tid - 128) / 34;
+            (which ? SA4 : SA2)[q] = cmul((which ? S4 : S2)[t], (which ? T4 : T2)[2 + q]);
+        }
+        __syncthreads();                                        // xs and SA complete
+        // ---- the next tile's raw chunk: requested now, it lands under the FIR ----
+        pre = make_uint4(0u, 0u, 0u, 0u);
+        if (t + 1 < ntl && tid < tl[t + 1].nchunk) pre = ffast_chunk(base, tl[t + 1].first_al + 8L * tid, n0);
+        // ---- pass 1: filter(coef,1,.) -> buf0 ----
+#pragma unroll 1
+        for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * ST_THREADS) {
+            cplx y[4];
+            fir4_sym47(xs, cf, i0, y);
+            // (all four stored: buf0 has room up to the next multiple of four, and the samples behind the span are staged as zeros.
+            // With the last three stores conditional the compiler sinks their outputs' FMAs under the conditions and keeps all
+            // fifty samples alive across them: 200 registers and a scratch frame)
+            buf0[i0] = y[0]; buf0[i0 + 1] = y[1]; buf0[i0 + 2] = y[2]; buf0[i0 + 3] = y[3];
+        }
+        __syncthreads();                                        // (xs is dead: buf1 may be written)
+        // ---- pass 2: level 1 = interp1 (FCCH_fine_correction.m:123-125), level 2 = .* exp(1i*k*c2) (:165) -> buf1 ----
+        {
+            const double dlo2 = (double)lo2, dlo0 = (double)lo0;
+            const int last0 = cnt0 - 1;
+            for (int i = tid; i < cnt2; i += ST_THREADS) {
+                const double xq = (dlo2 + (double)i) * f1;
+                const double j0f = floor(xq);
+                const int j0 = (int)(j0f - dlo0);
+                const int j1 = j0 + 1 > last0 ? last0 : j0 + 1;
+                const double tt = xq - j0f;
+                const cplx v0 = buf0[j0], v1 = buf0[j1];
+                const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
+                buf1[i] = cmul(v, cmul(SA2[i >> 5], b2));
+            }
+        }
+        __syncthreads();
+        // ---- pass 3: level 3 = interp1 (SCH_corr_rate_correction.m:126-127), level 4 = .* exp(1i*k*c4) (carrier_correct_post_SCH.m:83) ----
+        cplx* dst = a.dst + (size_t)s * a.dst_stream_stride + lo3;
+        {
+            const double dlo3 = (double)lo3, dlo2 = (double)lo2;
+            const int last2 = cnt2 - 1;
+            for (int i = tid; i < L4; i += ST_THREADS) {
+                const double xq = (dlo3 + (double)i) * f3;
+                const double j0f = floor(xq);
+                const int j0 = (int)(j0f - dlo2);
+                const int j1 = j0 + 1 > last2 ? last2 : j0 + 1;
+                const double tt = xq - j0f;
+                const cplx v0 = buf1[j0], v1 = buf1[j1];
+                const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
+#ifdef GSMCAL_EXP_NOSTORE      /* development experiment: the kernel without its 16 B/sample of output traffic */
+                if (a.dst_stream_stride < 0) dst[i] = cmul(v, cmul(SA4[i >> 5], b4));
+                else buf0[i] = cmul(v, cmul(SA4[i >> 5], b4));
+#else
+                dst[i] = cmul(v, cmul(SA4[i >> 5], b4));
+#endif
+            }
+        }
+        __syncthreads();                                        // buf1 (= xs) and SA may be rewritten
     }
 }
 
