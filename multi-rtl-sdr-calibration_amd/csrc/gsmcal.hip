@@ -102,6 +102,7 @@ struct gsmcal_ctx {
     bool post_repl = true;          // GSMCAL_POST_REPL=0: k_post_chain (last arriver decides, state through memory) instead of k_post_chain_r
     bool lane_stagger = false;      // GSMCAL_LANE_STAGGER=1: calibration lanes start one front kernel apart instead of together
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
+    bool fcert_s47 = true;          // GSMCAL_FCERT_S47=0: k_fine_cert builds its windows with the LDS-tap FIR loop also for the 47-tap symmetric filter
     bool stream_s47 = true;         // GSMCAL_STREAM_S47=0: the general k_stream_tile also for the 47-tap symmetric filter
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
@@ -405,6 +406,9 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             if ((per + src.ntaps + 14) / 8 + 1 <= fc_thr && fc_stage_bytes(per, src.ntaps) <= avail) {
                 fg.raw = src.raw; fg.raw_stride = src.raw_stride; fg.coef = src.coef; fg.win_out = win;
                 fg.ntaps = src.ntaps; fg.per = per;
+                bool sym = src.ntaps == 47 && (int)c->h_coef.size() == 47 && c->fcert_s47;
+                for (int k = 0; sym && k < 23; ++k) sym = c->h_coef[k] == c->h_coef[46 - k];
+                fg.sym47 = sym ? 1 : 0;
                 break;
             }
         }
@@ -1041,6 +1045,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (pse && atoi(pse) >= 1) c->post_slots_cap = atoi(pse);
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
+    const char* f47 = getenv("GSMCAL_FCERT_S47");
+    if (f47) c->fcert_s47 = atoi(f47) != 0;
     const char* s47 = getenv("GSMCAL_STREAM_S47");
     if (s47) c->stream_s47 = atoi(s47) != 0;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
@@ -1745,8 +1751,11 @@ static RcclApi* rccl_api() {
     // RCCL must belong to the HIP runtime this process runs on: a process whose runtime is the copy bundled with a
     // PyTorch-ROCm wheel and whose RCCL is the system one works until exit and then aborts in the allocator (double free).
     // So: a librccl that is mapped already; else the one lying beside the loaded libamdhip64; else the loader's choice.
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    // (RTLD_NODELETE throughout: RCCL registers exit-time clean-up of its own; a process that unloads the library before that
+    // runs -- a Python interpreter tearing down its ctypes handles in no particular order -- ends in the allocator with
+    // "double free or corruption" after all work is done and checked)
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD | RTLD_NODELETE);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD | RTLD_NODELETE);
     if (!h) {
         Dl_info di;
         if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
@@ -1754,14 +1763,14 @@ static RcclApi* rccl_api() {
             const size_t cut = dir.rfind('/');
             if (cut != std::string::npos) {
                 dir.resize(cut + 1);
-                h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
-                if (!h) h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+                h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
+                if (!h) h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
             }
         }
     }
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
     if (!h) return nullptr;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");

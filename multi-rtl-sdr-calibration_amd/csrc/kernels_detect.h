@@ -1679,6 +1679,7 @@ struct FusedGather {
     const double* coef;
     cplx* win_out;
     int ntaps, per;           // per: outputs per staging pass (multiple of 4)
+    int sym47, pad;           // sym47: 47 exactly mirrored taps (the drivers' fir1(46)): taps in registers, every sample read once (fir4_sym47)
 };
 // staging bytes of one pass: padded complex input | coefficients
 __host__ inline size_t fc_stage_bytes(int per, int ntaps) {
@@ -1750,6 +1751,12 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         const unsigned short* base = (const unsigned short*)(fg.raw + (size_t)s * fg.raw_stride);
         cplx* wout = fg.win_out + (size_t)s * win_stream_stride + (size_t)w * win_stride;
         fir_stage_taps(c_s, fg.coef, ntp, tid, nthr);
+        const bool sym47 = OV > 0 && NTAPS == 47 && fg.sym47 != 0;      // (block-uniform)
+        double cf[24];                                                // the 24 distinct taps (uniform addresses: scalar loads)
+        if (OV > 0 && NTAPS == 47) {
+#pragma unroll
+            for (int k = 0; k < 24; ++k) cf[k] = fg.coef[k];
+        }
         // raw chunk `tid` of a pass (8 samples, 16-byte aligned), fetched one pass ahead so the loads overlap the FIR of
         // the previous one; samples outside the stream read as 0 and are zeroed again after the mean is subtracted
         const long ao = (long)(((uintptr_t)base >> 1) & 7);
@@ -1811,7 +1818,11 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
             }
             for (int i0 = 4 * tid; i0 < cnt; i0 += 4 * nthr) {
                 cplx y0, y1, y2, y3;              // gather_core's loop: every accumulator takes its taps oldest first
-                if (ntp == 47) fir4_lds<47>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
+                if (OV > 0 && NTAPS == 47 && sym47) {   // same sums, bit for bit: 50 LDS reads per four outputs instead of 72
+                    cplx y[4];
+                    fir4_sym47(xq, cf, i0, y);
+                    y0 = y[0]; y1 = y[1]; y2 = y[2]; y3 = y[3];
+                } else if (ntp == 47) fir4_lds<47>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
                 else fir4_lds<0>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
                 const int o = o0 + i0;
                 xs[FC_XP(o)] = y0; wout[o] = y0;
