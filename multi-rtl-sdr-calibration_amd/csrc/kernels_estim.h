@@ -421,7 +421,68 @@ __device__ __forceinline__ void burst_tone_body(StreamState* __restrict__ sts, c
 // Stores SCH_pos(i) = sp + max_idx - 1 into st->sch_first[w]; an edge peak sets st->sch_edge (:59).
 // ------------------------------------------------------------------------------------------------
 #define SCH_PARTS 4
-template <int FIR_UNR = 1>
+// ------------------------------------------------------------------------------------------------
+// The correlation for the drivers' geometry (NSH = 89 offsets, LT = 512 taps), organised around LDS traffic (round 4: at
+// 1 024 streams the chain's time is the SUM of its VALU and LDS pipe times, and this loop -- two 16-byte LDS reads per
+// complex MAC -- was a ninth of all LDS cycles).  A lane takes R = 4 consecutive offsets and one of Q = 16 stretches of M = 39
+// window samples: per sample it reads the sample (the same address in every lane of its stretch: a broadcast) and ONE new tap
+// (its four offsets see the taps sliding by one per sample), and issues four complex MACs -- 2 reads per 16 FMAs instead of
+// 2 per 4.  conj(ts) is staged zero-padded on both sides, so taps outside the sequence multiply as zeros and no lane tests
+// an index; the stretches of one offset group are the 16 lanes of a DPP row, which adds them up without LDS.  The 39-sample
+// stride (624 B) puts the 16 lanes of a row on 16 different bank groups for both reads.  cv[o] = |sch_ts' * window_o|^2.
+// tcp: (R*NG + Q*M) entries; xs_w: the window, writable up to Q*M entries (the gather buffers have len + 40).
+// ------------------------------------------------------------------------------------------------
+template <int NSH, int LT>
+__device__ __forceinline__ void sch_corr_rows(cplx* __restrict__ xs_w, const cplx* __restrict__ ts, cplx* __restrict__ tcp,
+                                              double* __restrict__ cv, int tid, int nthreads) {
+    constexpr int R = 4, Q = 16, M = 39;
+    constexpr int NG = (NSH + R - 1) / R, PADL = R * NG, NTC = PADL + Q * M, WL = NSH - 1 + LT;
+    static_assert(Q * M >= WL && Q * M <= WL + 40, "the stretches cover the window and stay inside the gather buffer's slack");
+    for (int i = tid; i < NTC; i += nthreads) {
+        const int n = i - PADL;
+        tcp[i] = (n >= 0 && n < LT) ? make_double2(ts[n].x, -ts[n].y) : make_double2(0.0, 0.0);
+    }
+    for (int i = WL + tid; i < Q * M; i += nthreads) xs_w[i] = make_double2(0.0, 0.0);   // finite values behind the window (their taps are zeros)
+    __syncthreads();
+    if (tid < NG * Q) {
+        const int g = tid >> 4, q = tid & 15;
+        const cplx* __restrict__ xp = xs_w + q * M;
+        const cplx* __restrict__ tp = tcp + PADL + q * M - R * g;     // tp[s - j]: tap of offset 4g+j at sample q*M + s
+        cplx T1 = tp[-1], T2 = tp[-2], T3 = tp[-3];
+        double ar0 = 0.0, ai0 = 0.0, ar1 = 0.0, ai1 = 0.0, ar2 = 0.0, ai2 = 0.0, ar3 = 0.0, ai3 = 0.0;
+#define SCH_MAC(AR, AI, C, V) AR = fma(C.x, V.x, fma(-C.y, V.y, AR)); AI = fma(C.x, V.y, fma(C.y, V.x, AI));
+#define SCH_STEP(S, TA, TB, TC, TD) { const cplx xv = xp[S]; TA = tp[S]; SCH_MAC(ar0, ai0, TA, xv) SCH_MAC(ar1, ai1, TB, xv) SCH_MAC(ar2, ai2, TC, xv) SCH_MAC(ar3, ai3, TD, xv) }
+        cplx T0;
+        int s = 0;
+#pragma unroll 1
+        for (; s + 4 <= M; s += 4) {                                  // four samples per trip: the tap window rotates by renaming
+            SCH_STEP(s, T0, T1, T2, T3)
+            SCH_STEP(s + 1, T3, T0, T1, T2)
+            SCH_STEP(s + 2, T2, T3, T0, T1)
+            SCH_STEP(s + 3, T1, T2, T3, T0)
+        }
+        static_assert(M % 4 == 3, "three samples left");
+        SCH_STEP(s, T0, T1, T2, T3)
+        SCH_STEP(s + 1, T3, T0, T1, T2)
+        SCH_STEP(s + 2, T2, T3, T0, T1)
+#undef SCH_STEP
+#undef SCH_MAC
+        // the 16 stretches of an offset group are one DPP row: xor 1, xor 2, half-row mirror, row mirror leave the row's total in every lane
+#define SCH_ROWSUM(V) V += dpp_move_f64<0xB1, 0xF>(V); V += dpp_move_f64<0x4E, 0xF>(V); V += dpp_move_f64<0x141, 0xF>(V); V += dpp_move_f64<0x140, 0xF>(V);
+        SCH_ROWSUM(ar0) SCH_ROWSUM(ai0) SCH_ROWSUM(ar1) SCH_ROWSUM(ai1) SCH_ROWSUM(ar2) SCH_ROWSUM(ai2) SCH_ROWSUM(ar3) SCH_ROWSUM(ai3)
+#undef SCH_ROWSUM
+        const double sr = q == 0 ? ar0 : (q == 1 ? ar1 : (q == 2 ? ar2 : ar3)), si = q == 0 ? ai0 : (q == 1 ? ai1 : (q == 2 ? ai2 : ai3));
+        const int o = R * g + q;
+        if (q < R && o < NSH) {
+            const double m = hypot(sr, si);
+            cv[o] = m * m;                                            // :53 abs(...).^2
+        }
+    }
+    __syncthreads();
+}
+
+// FAST: the drivers' geometry (11*8+1 = 89 offsets, 512-sample training sequence): sch_corr_rows
+template <int FIR_UNR = 1, bool FAST = false>
 __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, const GatherArgs& a,
                                                 const cplx* __restrict__ ts, int len_ts, int nshift,
                                                 unsigned char* smem, double* res = nullptr) {   // res: {SCH_pos, edge flag}
@@ -436,6 +497,10 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
     double* cv = (double*)(part + nshift * SCH_PARTS);                    // nshift correlation powers
     __syncthreads();
     StreamState* st = sts + s;
+    if (FAST) {
+        // (its zero-padded tap copy, 92 + 624 entries, and the 89 powers take less room than tc | part | cv above)
+        sch_corr_rows<89, 512>(xs, ts, tc, cv, tid, 512);
+    } else {
     for (int i = tid; i < len_ts; i += 512) tc[i] = make_double2(ts[i].x, -ts[i].y);
     __syncthreads();
     const int seg = (len_ts + SCH_PARTS - 1) / SCH_PARTS;
@@ -480,6 +545,7 @@ __device__ __forceinline__ void window_sch_body(StreamState* __restrict__ sts, c
         cv[o] = m * m;                      // :53 abs(...).^2
     }
     __syncthreads();
+    }
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 2);
     if (tid < 64) {                                       // first maximum over the offsets: one wave, then a shuffle tree
         int mi = 0x7fffffff;
@@ -970,7 +1036,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
     GatherArgs a = a_in;
     const int len_ts = OV > 0 ? LT : len_ts_rt, nshift = OV > 0 ? 11 * OV + 1 : nshift_rt;
     if (OV > 0) { a.len = 11 * OV + LT; a.ntaps = NTAPS; a.src_kind = SRC_RAW; a.tiles = 0; a.level = 2; }
-    window_sch_body<(OV > 0 ? 2 : 1)>(sts, a, ts, len_ts, nshift, smem);
+    window_sch_body<(OV > 0 ? 2 : 1), (OV == 8 && LT == 512)>(sts, a, ts, len_ts, nshift, smem);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 3);
     stream_tail(sts, tail, smem, KID_SCH);
     DEV_STAMP(KID_SCH, blockIdx.y * gridDim.x + blockIdx.x, 4);
@@ -1221,7 +1287,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     // ---- stage 2: SCH_corr_rate_correction.m:45-55 -> SCH_DECIDE (:59-181) + post-SCH window setup ----
     const int n_sch_win = sh->n_win;
     PCR_PRIO(0, 1, 2)                                               // (the deciding wave returns to its round's priority)
-    window_sch_body<(OV > 0 ? 2 : 1)>(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
+    window_sch_body<(OV > 0 ? 2 : 1), (OV == 8 && LT == 512)>(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 7);
     pcr_exchange(mine_x + 2 * XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);

@@ -46,6 +46,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// the same for 32-bit unsigned integers (exact: no overflow is the caller's business); the total is returned in every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_move_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+    v += dpp_move_u32<0xB1, 0xF>(v);
+    v += dpp_move_u32<0x4E, 0xF>(v);
+    v += dpp_move_u32<0x141, 0xF>(v);
+    v += dpp_move_u32<0x140, 0xF>(v);
+    v += dpp_move_u32<0x142, 0xA>(v);
+    v += dpp_move_u32<0x143, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Inclusive prefix sum over the lanes of the wave (lane l gets v_0 + ... + v_l): row_shr 1, 2, 4, 8 inside the 16-lane
 // rows, then the two row broadcasts.
 __device__ __forceinline__ double wave_scan_incl(double v) {
@@ -423,8 +438,16 @@ __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ 
     // block drift apart freely (loads of one overlap the arithmetic of another).
     {
         uint4 v[8];
+        // every block but the first and the last of a capture lies wholly inside it: eight plain 16-byte loads off one lane
+        // pointer (the per-chunk range tests of ffast_chunk were an eighth of this kernel's vector instructions)
+        if (first_al >= 0 && first_al + 8L * 2048 <= n) {       // (block-uniform)
+            const uint4* p = (const uint4*)(base + first_al) + (512 * wave + lane);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = ffast_chunk(base, first_al + 8L * (512 * wave + lane + 64 * u), n);
+            for (int u = 0; u < 8; ++u) v[u] = p[64 * u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ffast_chunk(base, first_al + 8L * (512 * wave + lane + 64 * u), n);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) *(uint4*)(r_s + 8 * ffast_slot(512 * wave + lane + 64 * u)) = v[u];
     }
@@ -451,12 +474,9 @@ __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ 
             sq = __builtin_amdgcn_udot4(e[i], 0x01000100u, sq, false);
         }
     }
-    {   // exact byte sums per wave; consumers add the 4*gridDim.x partials of the stream (integers: any order)
-        unsigned long long ti = si, tq = sq;
-        for (int off = 32; off > 0; off >>= 1) {
-            ti += __shfl_down(ti, off, 64);
-            tq += __shfl_down(tq, off, 64);
-        }
+    {   // exact byte sums per wave; consumers add the 4*gridDim.x partials of the stream (integers: any order).  A lane's sum is
+        // below 2^15 and a wave's below 2^21: 32-bit adds through DPP moves (seven instructions per sum, no LDS-crossbar shuffles)
+        const unsigned ti = wave_sum_u32(si), tq = wave_sum_u32(sq);
         if (lane == 0) {
             unsigned long long* p = partial + (((size_t)s * gridDim.x + blockIdx.x) * 4 + wave) * 2;
             p[0] = ti;
