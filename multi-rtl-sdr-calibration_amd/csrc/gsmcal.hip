@@ -100,7 +100,7 @@ struct gsmcal_ctx {
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
     bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
     bool post_repl = true;          // GSMCAL_POST_REPL=0: k_post_chain (last arriver decides, state through memory) instead of k_post_chain_r
-    bool lane_stagger = false;      // GSMCAL_LANE_STAGGER=1: calibration lanes start one front kernel apart instead of together
+    int lane_stagger = -1;          // GSMCAL_LANE_STAGGER=0/1: calibration lanes start together / one front kernel apart; -1 (default): apart from 256 streams per lane on
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool fcert_s47 = true;          // GSMCAL_FCERT_S47=0: k_fine_cert builds its windows with the LDS-tap FIR loop also for the 47-tap symmetric filter
     bool stream_s47 = true;         // GSMCAL_STREAM_S47=0: the general k_stream_tile also for the 47-tap symmetric filter
@@ -1038,7 +1038,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     const char* pre_ = getenv("GSMCAL_POST_REPL");
     if (pre_) c->post_repl = atoi(pre_) != 0;
     const char* lse = getenv("GSMCAL_LANE_STAGGER");
-    if (lse) c->lane_stagger = atoi(lse) != 0;
+    if (lse) c->lane_stagger = atoi(lse) != 0 ? 1 : 0;
     const char* fpe = getenv("GSMCAL_FUSE_POST");
     if (fpe) c->fuse_post = atoi(fpe) != 0;
     const char* pse = getenv("GSMCAL_POST_SLOTS");
@@ -1665,12 +1665,17 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         const int lo = L.lo, S = L.n;
         const uint8_t* raw_i = d_raw + (size_t)lo * 2 * n;
         RET_IF(ensure(c, L.dec, (size_t)S * nd * sizeof(cplx)));
-        if (nl > 1 && c->lane_stagger) {                    // staggered lanes: this lane's front kernel starts when the previous lane's has finished
+        // staggered lanes: this lane's front kernel starts when the previous lane's has finished -- the bandwidth-bound front kernels
+        // then follow one another instead of competing, and each runs beside the compute-bound stages of the lanes ahead of it.
+        // Measured (round 4, tools/s10.sh): 128 / 256 / 512 / 1 024 / 2 048 streams 0.345 / 0.562 / 1.002 / 1.807 / 3.629 ms staggered
+        // against 0.349 / 0.554 / 1.002 / 1.874 / 3.715 together: worth it from 256 streams per lane on.
+        const bool stagger = nl > 1 && (c->lane_stagger == 1 || (c->lane_stagger < 0 && d / nl >= 256));   // (one decision for all lanes of the call)
+        if (stagger) {
             if (!L.front_done) HIPCHK(c, hipEventCreateWithFlags(&L.front_done, hipEventDisableTiming));
             if (i > 0) HIPCHK(c, hipStreamWaitEvent(L.stream, c->lanes[i - 1].front_done, 0));
         }
         RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));  // :107,110,117
-        if (nl > 1 && c->lane_stagger) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
+        if (stagger) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
         RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));         // :117 (+ state init, fine setup)
         Source src{SRC_RAW, raw_i, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = cf_all + lo;
