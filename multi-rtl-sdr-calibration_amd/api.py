@@ -404,6 +404,22 @@ def calibrate_batch(raw, coef, sch_training_sequence, carrier_freq, want_r=False
     return out
 
 
+def calibrate_batch_dev(d_raw, d, n, coef, sch_training_sequence, carrier_freq, d_table, d_pos_info=None, d_r_correct=None,
+                        d_r_len=None, ctx=None):
+    """Device-pointer form of calibrate_batch: only enqueues on the context's stream (ctx.sync() before reading the outputs).
+    d_raw: [d][2n] bytes; d_table: [d][TABLE_COLS] doubles in any memory the GPU can store to (device or pinned host);
+    optional d_pos_info [d][2][MAX_POS_ROWS], d_r_correct [d][n] complex, d_r_len [d] int64.  carrier_freq: scalar or [d]."""
+    ctx = ctx or default_context()
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    ts = np.ascontiguousarray(np.asarray(sch_training_sequence, dtype=np.complex128).ravel())
+    cf = np.ascontiguousarray(np.broadcast_to(np.asarray(carrier_freq, dtype=np.float64), (int(d),)))
+    vp = lambda p: C.c_void_p(p) if p else None  # noqa: E731
+    ctx.check(ctx.lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(d_raw), int(d), int(n), _dp(coef), len(coef),
+                                                 _dp(ts), len(ts), _dp(cf),
+                                                 C.c_void_p(d_table), vp(d_pos_info), vp(d_r_correct), vp(d_r_len)),
+              "calibrate_batch_dev")
+
+
 def fcch_scan_batch_dev(d_raw, d, n, coef, d_snr_numhit, d_positions=None, d_pos_snr=None, d_counts=None, ctx=None):
     """Device-pointer form of fcch_scan_batch: only enqueues (call ctx.sync() before reading the outputs).
     d_raw: [d][2n] bytes; d_snr_numhit: [d][2] doubles; optional [d][MAX_HITS] doubles x2 and [d] ints."""

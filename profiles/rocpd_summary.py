@@ -4,6 +4,7 @@
     python profiles/rocpd_summary.py stats  <results.db> <out.csv> [skip_first_n_per_kernel]
     python profiles/rocpd_summary.py pmc    <fetch.db> <write.db> <out.json> <streams> <samples_per_stream>
     python profiles/rocpd_summary.py sq     <sq.db> <out.csv>
+    python profiles/rocpd_summary.py valu   <out.json> <regime>=<sq.db>:<launches per step> ...
 
 stats: per-kernel launch count, total / average / min / max duration (ns) -- the `--kernel-trace --stats` table.
 sq:    per-kernel means of every counter of an SQ pass (rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
@@ -98,8 +99,38 @@ def pmc(fetch_db, write_db, out, streams, samples):
                    "raw_kib_per_launch": raw, "hbm_bytes_per_launch": hbm}, fh, indent=1)
 
 
+def valu(out, specs):
+    """specs: regime=sq.db:launches_per_step ... -> wave-level VALU instructions per step of each regime (bench.py's
+    roofline_compute.valu_issue_util reads this file)"""
+    res = {"method": "rocprofv3 --pmc SQ_INSTS_VALU (the SQ pass of each regime): wave-level VALU instructions per launch, averaged over "
+                     "launches, times the launches per step of the regime's plan; kernels seen fewer than 4 times (stream selection) left out",
+           "peak_wave_instr_per_s": 256 * 4 * 2.4e9 / 4}
+    for spec in specs:
+        regime, rest = spec.split("=", 1)
+        db, lps = rest.rsplit(":", 1)
+        lps = int(lps)
+        cur = sqlite3.connect(db).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        name_col = "kernel_name" if "kernel_name" in cols else "name"
+        val_col = "value" if "value" in cols else "counter_value"
+        cn_col = "counter_name" if "counter_name" in cols else "pmc_name"
+        rows = cur.execute(f"select {name_col}, {cn_col}, {val_col}, dispatch_id from counters_collection").fetchall()
+        per = {}
+        for name, cn, val, did in rows:
+            if cn != "SQ_INSTS_VALU" or not short(name).startswith("k_"):
+                continue
+            per.setdefault(short(name), {}).setdefault(did, 0.0)
+            per[short(name)][did] += float(val)
+        det = {k: int(round(sum(v.values()) / len(v) * lps)) for k, v in per.items() if len(v) >= 4}
+        res[regime] = {"valu_wave_instr_per_step": int(sum(det.values())), "per_kernel": det, "launches_per_step_per_kernel": lps}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "valu":
+        valu(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3])

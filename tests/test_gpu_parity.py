@@ -592,6 +592,42 @@ def test_native_allgather_of_the_table_single_rank(g, ctx, setup, tmp_path):
         ctx.free(d_loc); ctx.free(d_all)
 
 
+@pytest.mark.parametrize("mode", ["inline", "async"])
+def test_native_table_gatherer_single_rank(g, ctx, setup, mode):
+    """bench.py's N > 1 exchange step on the C ABI's own collective (gsmcal.dist.NativeTableGatherer): the all-gather in line
+    on the context's stream, and on the library's side stream behind an event (gsmcal_allgather_table_async /
+    gsmcal_allgather_wait) -- two buffer pairs alternating over several steps of a real calibration, the gathered table equal to
+    the local one every time (one rank; the multi-rank layout is covered under gloo on CPU and by tests/multigpu_check.py)."""
+    import torch
+    from gsmcal import dist as gd
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=61)[0] for d in (20, 21, 22)])
+    ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)["table"]
+    dev = torch.device("cuda", 0)
+    raw_t = torch.from_numpy(raw).to(dev)
+    tabs = [torch.zeros((3, g.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(2)]
+    comm = gd.NativeComm(ctx, 1, 0, unique_id=gd.NativeComm.unique_id(ctx))
+    try:
+        tg = gd.NativeTableGatherer(ctx, comm, [3], g.TABLE_COLS, dev, mode=mode)
+        torch.cuda.synchronize()
+        for step in range(5):
+            b = step & 1
+            tg.wait(b)
+            tabs[b].zero_()
+            torch.cuda.synchronize()
+            g.calibrate_batch_dev(raw_t.data_ptr(), 3, raw.shape[1] // 2, setup["coef"], setup["ts"], np.full(3, FC), tabs[b].data_ptr(), ctx=ctx)
+            tg.post(b, tabs[b])
+        for b in range(2):
+            rows = tg.rows(b)
+            ctx.sync()
+            if mode == "async":
+                ctx.check(ctx.lib.gsmcal_allgather_sync(ctx.h, b), "gsmcal_allgather_sync")
+            assert np.array_equal(rows.cpu().numpy(), ref, equal_nan=True)
+            assert np.array_equal(tg.own_rows(b).cpu().numpy(), ref, equal_nan=True)
+    finally:
+        torch.cuda.synchronize()
+        comm.close()
+
+
 def test_SCH_equalise_front_end_of_the_demodulator(g, setup):
     """SURVEY 8f-4, SCH_demod.m:53-59,79-90: equalised SCH bursts (three 1552-point transforms and two spectral divisions per
     burst) from a really calibrated stream, against the oracle; plus the reference's early exit and index error."""
