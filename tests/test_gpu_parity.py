@@ -447,7 +447,8 @@ def test_front_end_variants_agree(g, setup, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"GSMCAL_CERT": "0"}, {"GSMCAL_PRESCREEN": "0"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2"},
                                  {"GSMCAL_FUSE_GATHER": "0"}, {"GSMCAL_SNR_FULL": "0"}, {"GSMCAL_SNR_SCREEN_DB": "-300"},
-                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}, {"GSMCAL_POST_REPL": "0"}])
+                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}, {"GSMCAL_POST_REPL": "0"},
+                                 {"GSMCAL_FCERT_S47": "0"}, {"GSMCAL_POST_SLOTS": "2"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2", "GSMCAL_LANE_STAGGER": "1"}])
 def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     """No certificate (every chunk swept), plain all-bin fp64 search, four concurrent lanes, fine windows through k_gather,
     hop walk on its own spectra / on an unscreened SNR table / falling back because the screening level is above every
@@ -465,6 +466,56 @@ def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
         other.close() if hasattr(other, "close") else None
     assert np.array_equal(ref["table"], out["table"], equal_nan=True)
     assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
+
+
+def test_stream_mode_kernels_agree_to_rounding_and_with_the_oracle_on_unaligned_captures(g, setup, monkeypatch):
+    """r_correct from k_stream_tile_s47 (the drivers' 47 symmetric taps: taps in registers, 952-sample tiles) and from the general
+    k_stream_tile (GSMCAL_STREAM_S47=0, 1016-sample tiles): the same filter sums in the same order; the rotators
+    exp(1i*k*c) = S*A*B are factored per TILE (S = exp(1i*fl(k0*c)) with the tile's first index k0), so the two tilings differ by
+    the rounding of the three ARGUMENTS -- up to 2 ulp(k*c) ~ 1e-11 rad at k ~ 6e5, the accuracy DESIGN.md states for the
+    rotator tables -- and by nothing else: 1e-10 of the peak here, against the 2e-8 bar on the oracle -- on captures whose length is odd (streams after the first start off a 16-byte boundary) and is
+    no multiple of either tile, and on taps that are symmetric only to the last ulp (scipy's firwin: the general kernel)."""
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=61)[0][: 2 * 609991] for d in (20, 21, 22)])
+    a = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, want_r=True)
+    monkeypatch.setenv("GSMCAL_STREAM_S47", "0")
+    other = g.Context(0)
+    monkeypatch.delenv("GSMCAL_STREAM_S47")
+    try:
+        b = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, want_r=True, ctx=other)
+    finally:
+        other.close()
+    assert np.array_equal(a["table"], b["table"], equal_nan=True) and np.array_equal(a["r_len"], b["r_len"])
+    checked = 0
+    for i in range(3):
+        L = int(a["r_len"][i])
+        if L < 0:
+            continue
+        diff = np.max(np.abs(a["r_correct"][i, :L] - b["r_correct"][i, :L]))
+        assert diff <= 1e-10 * np.max(np.abs(b["r_correct"][i, :L])), f"the two stream kernels differ by more than the rotator tables' rounding: {diff}"
+        orc = o.calibrate_stream(raw[i], setup["coef"], setup["ts"], FC, keep_r=True)
+        assert L == len(orc["r_correct"])
+        stream_close(a["r_correct"][i, :L], orc["r_correct"])
+        checked += 1
+    assert checked >= 1
+    gen = o.fir1(46, 200e3 / g.synth.FS)                       # not exactly mirrored: must take the general kernel, same answer within rounding
+    c = g.calibrate_batch(raw, gen, setup["ts"], FC, want_r=True)
+    for i in range(3):
+        L = int(c["r_len"][i])
+        if L >= 0 and a["r_len"][i] == L:
+            stream_close(c["r_correct"][i, :L], a["r_correct"][i, :L])
+
+
+def test_1024_stream_batch_on_staggered_lanes(g, setup):
+    """1 024 streams in one call: four lanes of 256 whose front kernels follow one another (the default from 256 streams per lane
+    on) -- every copy of a stream gets the row it gets in a batch of its own."""
+    distinct = [g.synth.make_stream(dongle=60 + i, num_frames=61)[0] for i in range(8)]
+    ref = g.calibrate_batch(np.stack(distinct), setup["coef"], setup["ts"], FC)
+    raw = np.stack([distinct[i % 8] for i in range(1024)])
+    for _ in range(3):                                         # eager, graph capture, graph replay
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+        for i in range(1024):
+            assert np.array_equal(out["table"][i], ref["table"][i % 8], equal_nan=True), i
+        assert all(np.array_equal(out["pos_info"][i], ref["pos_info"][i % 8]) for i in range(0, 1024, 37))
 
 
 def test_large_batches_take_the_throughput_paths(g, setup):
