@@ -357,14 +357,28 @@ def main():
     # before a buffer is written again two steps later (gsmcal.dist.TableGatherer; uneven shards are padded).
     # N > 1: the C ABI's own all-gather, in line on the chain's stream (GSMCAL_BENCH_GATHER=async: on the library's side stream;
     # =torch: torch.distributed's collective, round 3's path) -- tools/dist_cost.py has what each costs per step on one rank
-    tg, gather_kind, ncomm = None, "none", None
+    tg, gather_kind, ncomm, gather_fallback = None, "none", None, None
     if use_dist:
         gather_kind = os.environ.get("GSMCAL_BENCH_GATHER", "native")
         if gather_kind == "torch":
             tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
         else:
-            ncomm = gdist.native_comm_from_process_group(ctx, dev)
-            tg = gdist.NativeTableGatherer(ctx, ncomm, sizes, gsmcal.TABLE_COLS, dev, mode="async" if gather_kind == "async" else "inline")
+            # (the native communicator has only ever run on one rank in this project's own sessions: if it cannot be set up on
+            # ANY rank, every rank falls back to torch.distributed's collective together and the line says so)
+            native_err = None
+            try:
+                if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back below)
+                    raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
+                ncomm = gdist.native_comm_from_process_group(ctx, dev)
+                tg = gdist.NativeTableGatherer(ctx, ncomm, sizes, gsmcal.TABLE_COLS, dev, mode="async" if gather_kind == "async" else "inline")
+            except Exception as e:  # noqa: BLE001
+                native_err = f"{type(e).__name__}: {e}"
+            bad = torch.tensor([0 if native_err is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                gather_fallback = native_err or "native communicator failed on another rank"
+                gather_kind, ncomm = "torch", None
+                tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
     host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
 
@@ -453,6 +467,8 @@ def main():
                    "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked,
                    "gathered_table_checked_against_every_rank": gathered_ok},
     }
+    if gather_fallback:
+        out["config"]["collective_fallback_from_native"] = gather_fallback
     if rank == 0:
         path_gbs = value * 1e6 * bps / 1e9
         roof = {"bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -6,6 +6,8 @@ resident in HBM, generated on the device); config 3: 2 dongles x 100 ARFCN throu
 The captures come from gsmcal_synth_expand_dev: a seeded set of synthetic GSM captures expanded on the device into
 distinct ones (rotation + counter-based dither); synth.expand_capture reproduces any of them bit for bit on the host,
 so sampled captures of the 16 GB batch go through the CPU oracle without the batch ever existing on the host."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,8 @@ import parity
 from oracle import gsmcal_oracle as o
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FRAMES = 64                      # multi_rtl_sdr_gsm_FCCH_scanner.m:39
 N = FRAMES * 10000               # 640 000 complex samples per capture
@@ -169,3 +173,33 @@ def test_ingest_ring_overlaps_copies_with_the_detector(g_mod, ctx):
         ref = g.fcch_scan_batch(batches[k], coef, ctx=ctx)
         assert np.array_equal(got[k, :, 0], ref["snr"]) and np.array_equal(got[k, :, 1], ref["num_hit"]), f"batch {k}"
     assert np.sum(got[:, :, 1] > 0) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_native", [False, True])
+def test_bench_distributed_step_on_one_rank_and_its_fall_back(fail_native):
+    """bench.py's N > 1 code path as the driver's 8-GPU run takes it, on one rank (GSMCAL_FORCE_DIST=1: process group, native
+    communicator, one all-gather per step, digest check of the gathered table) -- and the fall-back to torch.distributed's
+    collective on every rank together when the native communicator cannot be set up (it has never run on more than one rank
+    in this project's own sessions; a failure there must not cost the scaling record)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSMCAL_FORCE_DIST"] = "1"
+    if fail_native:
+        env["GSMCAL_BENCH_FAIL_NATIVE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--streams", "4", "--distinct", "4",
+           "--no-sub", "--no-cpu-baseline", "--no-kernel-events"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert p.returncode == 0 and line, p.stderr[-2000:]
+    r = json.loads(line[-1])
+    cfg = r["config"]
+    assert cfg["gathered_table_checked_against_every_rank"] is True
+    assert cfg["streams_calibrated_ok"] == 4
+    if fail_native:
+        assert cfg["collective"].endswith("torch.distributed over RCCL")
+        assert "GSMCAL_BENCH_FAIL_NATIVE" in cfg["collective_fallback_from_native"]
+    else:
+        assert "native RCCL" in cfg["collective"] and "collective_fallback_from_native" not in cfg
