@@ -329,7 +329,9 @@ int gsmcal_last_batch_details(gsmcal_ctx* ctx, int d, double* coarse_pos, double
  * the last batch call built for `stream`.  *n_moving entries are the moving search's windows (every one computed in full);
  * entries beyond them (latency path only, up to *n_table) serve the hop walk and hold -inf where a window was proved to be
  * below the screening level.  The decisions snr - avg > th are taken on these values: the parity suite measures how far they
- * sit from the oracle's (the implementation noise the certified scan's 1e-6 dB margin has to cover). */
+ * sit from the oracle's (the implementation noise the certified scan's 1e-6 dB margin has to cover).
+ * Batches of more than 128 streams per internal lane keep no table (the scan kernel computes the values in LDS):
+ * GSMCAL_E_UNSUPPORTED unless the context was created under GSMCAL_SNR_INLINE_KEEP=1. */
 int gsmcal_last_batch_snr(gsmcal_ctx* ctx, int stream, double* snr, long cap, long* n_table, long* n_moving);
 
 #ifdef __cplusplus

@@ -91,6 +91,8 @@ struct gsmcal_ctx {
     bool graph_always = false;      // GSMCAL_GRAPH=2: also single-stream plans (default: only plans that fork onto internal streams)
     bool prescreen = true;          // GSMCAL_PRESCREEN=0: run the fp64 fine search on every bin
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
+    int snr_inline_min = 1;         // GSMCAL_SNR_INLINE_MIN: streams per lane from which k_coarse_scan computes the window SNRs itself when the full table is not built (0: never)
+    int snr_inline_keep = 0;        // GSMCAL_SNR_INLINE_KEEP=1: ... and still writes the table out (gsmcal_last_batch_snr)
     int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
@@ -645,6 +647,7 @@ static const auto k_coarse_scan_lat = &k_coarse_scan<3, true>;   // (one registe
 static const auto k_coarse_scan_thr = &k_coarse_scan<3, true>;
 static const auto k_coarse_scan_gen = &k_coarse_scan<2, false>;
 static const auto k_coarse_scan_ref = &k_coarse_scan<3, true, true>;   // the drivers' window geometry as constants
+static const auto k_coarse_scan_inl = &k_coarse_scan<3, true, true, true>;   // ... with the window SNRs computed in place (throughput batches)
 
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
                 cplx* d_out, long out_stride) {
@@ -707,7 +710,7 @@ int ensure_head(gsmcal_ctx* c, int front_decim) {
 }
 
 int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int dec_ratio, int fine_setup_ov,
-           bool mean_corr = false, long n0 = 0, int front_decim = 64, const ScanAccept* accept = nullptr) {
+           bool mean_corr = false, long n0 = 0, int front_decim = 64, const ScanAccept* accept = nullptr, bool allow_inline = true) {
     CoarseArgs a;
     memset(&a, 0, sizeof(a));
     if (accept) { a.accept = *accept; a.P = dev_params(c); }
@@ -754,11 +757,28 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
         if ((rest + sblocks - 1) / sblocks > CS_TILE - 3) sblocks = (unsigned)((rest + CS_TILE - 4) / (CS_TILE - 3));
         a.snr_tile = (int)((((rest + sblocks - 1) / sblocks) + 3) & ~3L);
     }
+    const bool refg = dec_ratio == 8 && fft_len == 16 && n_first == 3594;
+    // throughput batches (every batch too big for the full table above): the scan kernel computes the moving search's SNRs itself
+    // -- no table in HBM, one launch less: 200 / 800 captures 0.091 / 0.317 -> 0.088 / 0.303 ms, 1 024 streams 1.813 -> 1.782 ms.
+    // The table is written out only on request (GSMCAL_SNR_INLINE_KEEP=1); gsmcal_last_batch_snr has nothing to return otherwise.
+    // Not in the scanner's pipeline stages (allow_inline = false): there the one long kernel beside the next stage's front kernel
+    // costs more than the table's traffic (12 800 captures 3.85 -> 3.98 ms).
+    if (allow_inline && refg && a.snr_nwin == 0 && c->snr_inline_min > 0 && S >= c->snr_inline_min) {
+        a.snr_g = nullptr; a.snr_stride = ntab;
+        c->cur->snr_stride = 0; c->cur->snr_nmove = nwin;
+        if (c->snr_inline_keep) {
+            RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * ntab * sizeof(double)));
+            a.snr_g = (double*)c->cur->snrbuf.p;
+            c->cur->snr_stride = ntab;
+        }
+        LAUNCH(c, k_coarse_scan_inl, dim3(S), dim3(256), lds, (StreamState*)c->cur->state.p, a);
+        CHECK_LAUNCH(c);
+        return 0;
+    }
     RET_IF(ensure(c, c->cur->snrbuf, (size_t)S * ntab * sizeof(double)));
     a.snr_g = (double*)c->cur->snrbuf.p; a.snr_stride = ntab;
     c->cur->snr_stride = ntab; c->cur->snr_nmove = nwin;
     const dim3 sgrid(sblocks, S);
-    const bool refg = dec_ratio == 8 && fft_len == 16 && n_first == 3594;
     if (fft_len == 16 && a.snr_nwin > 0) LAUNCH_GEOM(refg, c, (k_coarse_snr<true, true, true>), (k_coarse_snr<true, true>), sgrid, dim3(CS_SNR_THREADS), 0, a);
     else if (fft_len == 16) LAUNCH_GEOM(refg, c, (k_coarse_snr<true, false, true>), (k_coarse_snr<true>), sgrid, dim3(256), 0, a);
     else LAUNCH(c, k_coarse_snr<false>, sgrid, dim3(256), 0, a);
@@ -995,6 +1015,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     (void)hipFuncSetAttribute((const void*)k_front_fast31, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_lat, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_thr, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_coarse_scan_inl, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_coarse_scan_ref, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     (void)hipFuncSetAttribute((const void*)k_burst_tone<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -1021,6 +1042,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     const char* e = getenv("GSMCAL_LANES");
     if (e && atoi(e) >= 1) c->n_lanes_cfg = atoi(e) > MAX_LANES ? MAX_LANES : atoi(e);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
+    if (const char* e2 = getenv("GSMCAL_SNR_INLINE_MIN")) c->snr_inline_min = atoi(e2);
+    if (const char* e2 = getenv("GSMCAL_SNR_INLINE_KEEP")) c->snr_inline_keep = atoi(e2);
     const char* sst = getenv("GSMCAL_SCAN_STAGES");
     if (sst && atoi(sst) >= 1) c->scan_stages = atoi(sst);
     const char* lm = getenv("GSMCAL_LANE_MIN");
@@ -1598,7 +1621,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         acc.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
         acc.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
         acc.counts = d_counts ? d_counts + lo : nullptr;
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, nl == 1));
         CHECK_LAUNCH(c);
     }
     RET_IF(join_lanes(c, nl));
@@ -2113,7 +2136,12 @@ int gsmcal_last_batch_snr(gsmcal_ctx* c, int stream, double* snr, long cap, long
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < c->n_lanes_used; ++i) {
         const Lane& L = c->lanes[i];
-        if (stream < L.lo || stream >= L.lo + L.n || !L.snrbuf.p || L.snr_stride <= 0) continue;
+        if (stream < L.lo || stream >= L.lo + L.n) continue;
+        if (L.snr_stride <= 0 && L.snr_nmove > 0) {
+            c->err = "the last batch kept no SNR table (throughput batches compute the window SNRs inside the scan kernel; GSMCAL_SNR_INLINE_KEEP=1 writes it out)";
+            return GSMCAL_E_UNSUPPORTED;
+        }
+        if (!L.snrbuf.p || L.snr_stride <= 0) continue;
         const long n = L.snr_stride < cap ? L.snr_stride : cap;
         HIPCHK(c, hipMemcpy(snr, (const double*)L.snrbuf.p + (size_t)(stream - L.lo) * L.snr_stride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         if (n_table) *n_table = L.snr_stride;

@@ -472,7 +472,10 @@ __host__ __device__ inline size_t coarse_scan_lds_fixed() {
     return ((sizeof(StreamState) + 15) & ~(size_t)15) + 64 * sizeof(cplx) + 4 * CS_ROW * sizeof(cplx) + (2 * 11 * 17 + 2 * MAXH) * sizeof(double);
 }
 
-template <int WAVES, bool FFT16, bool REFG = false>
+// INL (throughput batches, 16-point windows): the moving search's window SNRs are computed HERE, straight into the LDS copy the
+// scan reads -- k_coarse_snr<true,false>'s arithmetic, value for value -- so the table never makes the trip through HBM and the
+// k_coarse_snr launch in front of this kernel is gone (a.snr_g non-null: it is still written out, for gsmcal_last_batch_snr).
+template <int WAVES, bool FFT16, bool REFG = false, bool INL = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) k_coarse_scan(StreamState* __restrict__ sts, CoarseArgs a_in) {
     CoarseArgs a = a_in;
     if (REFG) { a.mode = 0; a.decimation_ratio = 8; }
@@ -514,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
             if (b < a.npartial) { pvi[k] = pp[2 * b]; pvq[k] = pp[2 * b + 1]; }
         }
     }
-    if (!bad && a.mode != 2) {
+    if (!INL && !bad && a.mode != 2) {
         const double* sg = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
         const long tot = mv_len + g.nwin + 64;
         for (long i0 = 0; i0 < tot; i0 += 16 * 256) {
@@ -580,6 +583,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
             }
     };
     if (!tw_lazy) make_tw();
+    if (INL && FFT16 && !bad && a.mode != 2) {
+        // k_coarse_snr<true, false>: 256 windows per round from the 271 raw samples they cover (the DC term is removed in the
+        // spectrum), the next round's samples requested before this round's spectra; then the head windows again with per-sample
+        // DC removal.  S = [999 x mv_len | snr | 0 x 64] as above.
+        const long nwin = g.nwin;
+        for (int i = tid; i < mv_len; i += 256) snr_s[i] = 999.0;
+        for (int i = tid; i < 64; i += 256) snr_s[mv_len + nwin + i] = 0.0;
+        cplx* xw = rows;                                  // 271 samples: the hop buffers (rows | Pb, 5.3 KB) are not in use yet
+        const cplx* sp = s.s;
+        const cplx z = make_double2(0.0, 0.0);
+        cplx c0 = tid < len ? sp[tid] : z, c1 = (tid < 15 && 256 + tid < len) ? sp[256 + tid] : z;
+        for (long b0 = 0; b0 < nwin; b0 += 256) {
+            xw[tid] = c0;
+            if (tid < 15) xw[256 + tid] = c1;
+            __syncthreads();
+            const long nb = b0 + 256;
+            if (nb < nwin) {
+                c0 = nb + tid < len ? sp[nb + tid] : z;
+                if (tid < 15) c1 = nb + 256 + tid < len ? sp[nb + 256 + tid] : z;
+            }
+            if (b0 + tid < nwin) snr_s[mv_len + b0 + tid] = window_snr16_from(s, xw + tid);
+            __syncthreads();
+        }
+        if (s.n_head > 0) {                               // (block-uniform)
+            cplx* hx = rows;
+            const int nh = s.n_head < 8 ? s.n_head : 8;
+            if (tid < nh + fft_len - 1 && tid < g.n_first) hx[tid] = dv_load(s, tid);
+            __syncthreads();
+            if (tid < nh && tid < nwin) snr_s[mv_len + tid] = window_snr16_head(hx + tid, s.floor2);
+        }
+        if (a.snr_g) {
+            __syncthreads();
+            double* tab = a.snr_g + (size_t)blockIdx.x * a.snr_stride;
+            for (long i = tid; i < nwin; i += 256) tab[i] = snr_s[mv_len + i];
+        }
+    }
     __syncthreads();
     const bool want_cert = !bad && a.mode == 0;
     if (tid == 0) {

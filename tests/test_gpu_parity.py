@@ -448,7 +448,8 @@ def test_front_end_variants_agree(g, setup, monkeypatch):
 @pytest.mark.parametrize("env", [{"GSMCAL_CERT": "0"}, {"GSMCAL_PRESCREEN": "0"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2"},
                                  {"GSMCAL_FUSE_GATHER": "0"}, {"GSMCAL_SNR_FULL": "0"}, {"GSMCAL_SNR_SCREEN_DB": "-300"},
                                  {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}, {"GSMCAL_POST_REPL": "0"},
-                                 {"GSMCAL_FCERT_S47": "0"}, {"GSMCAL_POST_SLOTS": "2"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2", "GSMCAL_LANE_STAGGER": "1"}])
+                                 {"GSMCAL_FCERT_S47": "0"}, {"GSMCAL_POST_SLOTS": "2"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2", "GSMCAL_LANE_STAGGER": "1"},
+                                 {"GSMCAL_SNR_FULL": "0", "GSMCAL_SNR_INLINE_MIN": "0"}])
 def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     """No certificate (every chunk swept), plain all-bin fp64 search, four concurrent lanes, fine windows through k_gather,
     hop walk on its own spectra / on an unscreened SNR table / falling back because the screening level is above every
@@ -466,6 +467,45 @@ def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
         other.close() if hasattr(other, "close") else None
     assert np.array_equal(ref["table"], out["table"], equal_nan=True)
     assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
+
+
+def test_window_snrs_computed_inside_the_scan_kernel_are_the_table_kernels(g, setup, monkeypatch):
+    """Throughput batches build no SNR table in HBM: k_coarse_scan<.., INL> computes the moving search's 3 579 window SNRs into
+    its LDS copy itself.  Forced here on a small batch (GSMCAL_SNR_FULL=0) and written out on request
+    (GSMCAL_SNR_INLINE_KEEP=1): every value bit for bit what k_coarse_snr stores (GSMCAL_SNR_INLINE_MIN=0), the same tables and
+    scanner outputs either way -- and without the request gsmcal_last_batch_snr says that nothing was kept."""
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=64)[0] for d in (30, 31)] +
+                   [g.synth.make_stream(dongle=32, num_frames=64, snr_db=6.0)[0], g.synth.make_stream(dongle=33, num_frames=64, bcch=False)[0]])
+    coef31 = g.synth.fir1(30, 200e3 / g.synth.FS)
+    made = {}
+    for name, env in (("kernel", {"GSMCAL_SNR_INLINE_MIN": "0"}), ("inline_kept", {"GSMCAL_SNR_INLINE_KEEP": "1"}), ("inline", {})):
+        monkeypatch.setenv("GSMCAL_SNR_FULL", "0")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        made[name] = g.Context(0)
+        for k in list(env) + ["GSMCAL_SNR_FULL"]:
+            monkeypatch.delenv(k)
+    try:
+        outs, tabs = {}, {}
+        for name, cx in made.items():
+            cal = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=cx)
+            if name == "inline":
+                with pytest.raises(g.GsmcalError, match="kept no SNR table"):
+                    g.last_batch_snr(0, ctx=cx)
+            else:
+                tabs[name] = [g.last_batch_snr(i, ctx=cx) for i in range(len(raw))]
+            outs[name] = (cal["table"], g.fcch_scan_batch(raw, coef31, ctx=cx))
+        for i in range(len(raw)):
+            (ta, na), (tb, nb) = tabs["kernel"][i], tabs["inline_kept"][i]
+            assert na == nb == 3579 and len(ta) == len(tb) == 3579
+            assert np.array_equal(ta, tb), f"stream {i}: inline window SNRs differ from k_coarse_snr's"
+        for name in ("inline_kept", "inline"):
+            assert np.array_equal(outs["kernel"][0], outs[name][0], equal_nan=True)
+            for k in outs["kernel"][1]:
+                assert np.array_equal(np.asarray(outs["kernel"][1][k]), np.asarray(outs[name][1][k]), equal_nan=True), (name, k)
+    finally:
+        for cx in made.values():
+            cx.close()
 
 
 def test_stream_mode_kernels_agree_to_rounding_and_with_the_oracle_on_unaligned_captures(g, setup, monkeypatch):
