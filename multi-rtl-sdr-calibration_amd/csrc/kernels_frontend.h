@@ -1186,6 +1186,9 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
 #ifndef ST47_TILE
 #define ST47_TILE 952
 #endif
+#ifndef ST47_MAXW
+#define ST47_MAXW 4           /* waves per SIMD the register allocation leaves room for */
+#endif
 __host__ __device__ constexpr size_t st47_xs_n(int tile) { return (size_t)(tile + 8 + 47 + 16) + (size_t)(tile + 8 + 47 + 16) / 4 + 2; }
 __host__ __device__ constexpr size_t st47_buf_n(int tile) { return (size_t)tile + 8 + 4; }
 __host__ __device__ inline size_t stream_tile_s47_lds(int tile = ST47_TILE) {
@@ -1241,7 +1244,7 @@ __device__ __forceinline__ void fir4_sym47(const cplx* __restrict__ xq, const do
 // this kernel's instructions), and the two accurate sincos per tile cost the wave that holds their lanes another ~200
 struct StTile { long lo0, lo2, lo3, first, first_al; int cnt0, cnt2, L4, nchunk; };
 template <int TILE>
-__global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(3, 4))) k_stream_tile_s47(const StreamState* __restrict__ sts, StreamTileArgs a) {
+__global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(3, ST47_MAXW))) k_stream_tile_s47(const StreamState* __restrict__ sts, StreamTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ StTile tl[ST_TPB];
     __shared__ cplx S2[ST_TPB], S4[ST_TPB];                     // exp(1i*fl(k0*c)) per tile and derotation
