@@ -677,6 +677,34 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         sub["config2_two_streams"] = {"streams": 2, "ms_per_call": round(1e3 * t, 4), "Msample_per_s": round(2 * N / t / 1e6, 1)}
         cal.launch(0)
         torch.cuda.synchronize(dev)
+    # the headline batch with its input in FOUR device buffers used in turn (4 x 130 MB: more than the 256 MB Infinity Cache), so
+    # that no step finds the raw bytes of an earlier one in a cache -- what a deployment fed by the ingest ring sees
+    if args.mode == "table":
+        try:
+            cals = [cal] + [Calib(torch, gsmcal, dev, ctx, cal.raw_t.clone(), N, "table", coef, ts, fc) for _ in range(3)]
+            kk = [0]
+
+            def rot():
+                c_ = cals[kk[0] & 3]
+                kk[0] += 1
+                c_.launch(0)
+                c_.to_host(0)
+            t = time_steps(torch, dev, rot, K, W + 4) / K
+            same = all(np.array_equal(c_.table(0).numpy(), cals[0].table(0).numpy(), equal_nan=True) for c_ in cals[1:])
+            v = cal.D * N / t / 1e6
+            sub["input_rotated_over_4_buffers"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
+                                                   "tables_identical_to_headline": bool(same),
+                                                   "what": "the headline step with the raw batch in four device buffers taken in turn "
+                                                           "(520 MB > the 256 MB Infinity Cache): every raw byte comes from HBM proper"}
+            if not args.no_kernel_events:
+                prof = event_pass(ctx, rot, 8, torch, dev)
+                sub["input_rotated_over_4_buffers"]["kernels_ms_per_step_untimed_pass"] = {k: round(v_[0] / 8, 4) for k, v_ in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            del cals
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            sub["input_rotated_over_4_buffers"] = {"error": repr(e)}
+        cal.launch(0)
+        torch.cuda.synchronize(dev)
     # the same streams with the corrected stream written (the API's real output, 18 B/sample)
     if args.mode == "table":
         cs = Calib(torch, gsmcal, dev, ctx, cal.raw_t, N, "stream", coef, ts, fc)
