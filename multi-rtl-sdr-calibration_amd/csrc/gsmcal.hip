@@ -93,6 +93,10 @@ struct gsmcal_ctx {
     int n_cu = 256;                 // compute units of the device (persistent-grid sizing)
     int snr_inline_min = 1;         // GSMCAL_SNR_INLINE_MIN: streams per lane from which k_coarse_scan computes the window SNRs itself when the full table is not built (0: never)
     int snr_inline_keep = 0;        // GSMCAL_SNR_INLINE_KEEP=1: ... and still writes the table out (gsmcal_last_batch_snr)
+    int front_nt = -1;              // GSMCAL_FRONT_NT: non-temporal raw loads in k_front_fast (-1: by the size of the call, see front_fused())
+    size_t call_raw_bytes = 0;      // raw bytes of the batch call in progress
+    int snr_inline_pipe = 1;        // GSMCAL_SNR_INLINE_PIPE=0: the two-kernel detector in the scanner's pipeline stages (the inline form is used there
+                                    // only while a stage's workgroups are all resident at once: 3 per CU)
     int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
@@ -667,7 +671,13 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
         // the production geometries (fir1(46) / fir1(30), 8x oversampling, aligned captures): rows in registers
         const size_t flds = (size_t)2048 * 16;              // swizzled, unpadded: five workgroups per CU
         c->cur->npartial = (int)nblk * 4;                  // this kernel writes one partial per wave
-#define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef, nd, d_out, out_stride)
+        // Raw bytes of a call that the Infinity Cache (256 MiB) cannot hold are read with non-temporal loads: 800 captures (1 GB)
+        // 199-216 -> 172-174 us = 6.7 TB/s for the kernel, the call 0.30-0.31 -> 0.276 ms; 12 800 captures 3.86 -> 3.75 ms.
+        // A smaller batch that the caller processes again (bench.py's 64 streams, 130 MB; 200 captures, 244 MiB) is served from the
+        // Infinity Cache from the second step on and keeps plain loads: there nt costs 1 us of 22.6 / 4 us of 88.
+        // GSMCAL_FRONT_NT=0/1 overrides.
+        const int nt = c->front_nt >= 0 ? c->front_nt : (c->call_raw_bytes > ((size_t)256 << 20) ? 1 : 0);
+#define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef, nd, d_out, out_stride, nt)
         if (ntaps == 47) { if (sym) FRONT_FAST(k_front_fast47_sym); else FRONT_FAST(k_front_fast47); }
         else { if (sym) FRONT_FAST(k_front_fast31_sym); else FRONT_FAST(k_front_fast31); }
 #undef FRONT_FAST
@@ -761,8 +771,9 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     // throughput batches (every batch too big for the full table above): the scan kernel computes the moving search's SNRs itself
     // -- no table in HBM, one launch less: 200 / 800 captures 0.091 / 0.317 -> 0.088 / 0.303 ms, 1 024 streams 1.813 -> 1.782 ms.
     // The table is written out only on request (GSMCAL_SNR_INLINE_KEEP=1); gsmcal_last_batch_snr has nothing to return otherwise.
-    // Not in the scanner's pipeline stages (allow_inline = false): there the one long kernel beside the next stage's front kernel
-    // costs more than the table's traffic (12 800 captures 3.85 -> 3.98 ms).
+    // In the scanner's pipeline stages only while the stage's workgroups are all resident at once (<= 3 per CU): with 800-capture
+    // stages the second, partial round of this long kernel beside the next stage's front kernel cost more than the table's
+    // traffic saved (12 800 captures 3.85 -> 3.98 ms); with 534-capture stages it wins (3.71 -> 3.69).
     if (allow_inline && refg && a.snr_nwin == 0 && c->snr_inline_min > 0 && S >= c->snr_inline_min) {
         a.snr_g = nullptr; a.snr_stride = ntab;
         c->cur->snr_stride = 0; c->cur->snr_nmove = nwin;
@@ -836,7 +847,9 @@ int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
     // kernels in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms for 12,800 captures), so big scanner
     // batches are cut into pipeline stages instead: the front kernels run one after the other (chained by events) and
     // each stage's detector runs underneath the next stage's front kernel.
-    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 8192 ? 16 : (d >= 2048 ? 8 : 1)));
+    // Stage size: about 550 captures (at least 8 stages) -- a stage of at most 3 x 256 captures lets its detector run as ONE
+    // resident round of k_coarse_scan<INL> workgroups (12 800 captures: 16 / 24 / 32 stages 3.75 / 3.69 / 3.71 ms).
+    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 2048 ? std::max(8, (d + 549) / 550) : 1));
     if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;
@@ -1044,6 +1057,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_MIN")) c->snr_inline_min = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_KEEP")) c->snr_inline_keep = atoi(e2);
+    if (const char* e2 = getenv("GSMCAL_FRONT_NT")) c->front_nt = atoi(e2);
+    if (const char* e2 = getenv("GSMCAL_SNR_INLINE_PIPE")) c->snr_inline_pipe = atoi(e2);
     const char* sst = getenv("GSMCAL_SCAN_STAGES");
     if (sst && atoi(sst) >= 1) c->scan_stages = atoi(sst);
     const char* lm = getenv("GSMCAL_LANE_MIN");
@@ -1595,6 +1610,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         return GSMCAL_E_INDEX;
     }
     c->cur = &c->lanes[0];
+    c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(ensure_head(c, decim));
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
@@ -1621,7 +1637,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         acc.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
         acc.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
         acc.counts = d_counts ? d_counts + lo : nullptr;
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, nl == 1));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, nl == 1 || (c->snr_inline_pipe && S <= 3 * c->n_cu)));
         CHECK_LAUNCH(c);
     }
     RET_IF(join_lanes(c, nl));
@@ -1668,6 +1684,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     int H = hits_capacity(nd, dec_ratio) + 1;
     if (H > MAXH) return GSMCAL_E_CAPACITY;
     c->cur = &c->lanes[0];
+    c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
     RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));

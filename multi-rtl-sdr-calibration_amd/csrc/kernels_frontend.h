@@ -401,6 +401,21 @@ __global__ void __launch_bounds__(256) k_front_fused(const uint8_t* __restrict__
 // of the staging stores (two rows, eight chunks each) and of the row loads (16 rows, one chunk index) -- touch
 // 16 different 16-byte bank groups, and the 2048 chunks take exactly 32 KB: five workgroups per CU instead of four.
 __device__ __forceinline__ int ffast_slot(int c) { return (c & ~7) | ((c & 7) ^ ((c >> 4) & 7)); }
+// 16 raw bytes that this launch reads exactly once: a non-temporal load (no claim on L2 / Infinity Cache lines that the
+// decimated rows and the detector's tables can use)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const uint4* p) {
+    const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// ... and 16 bytes of an output stream nobody in this launch reads back (r_correct, 1 GB per 64-stream step): stored non-temporal,
+// so that the step's input survives in the Infinity Cache (stream mode 0.766 -> 0.738 ms: the next step's front kernel 44 -> 23.5 us)
+__device__ __forceinline__ void st_stream16(cplx* p, const cplx v) {
+    typedef double f64x2_t __attribute__((ext_vector_type(2)));
+    f64x2_t o;
+    o.x = v.x; o.y = v.y;
+    __builtin_nontemporal_store(o, (f64x2_t*)p);
+}
 __device__ __forceinline__ uint4 ffast_chunk(const unsigned short* __restrict__ base, long g0, long n) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);                   // 8 samples from g0, zeros outside [0, n)
     if (g0 >= 0 && g0 + 8 <= n) {
@@ -419,7 +434,7 @@ template <int NT, bool SYM>
 __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ raw, long stream_bytes,
                                                     unsigned long long* __restrict__ partial,
                                                     const double* __restrict__ coef, long nd,
-                                                    cplx* __restrict__ out, long out_stride) {
+                                                    cplx* __restrict__ out, long out_stride, int nt_loads) {
     static_assert((NT & 1) == 1 && NT <= 49, "odd tap count that fits the 56-sample register window");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* r_s = (unsigned short*)smem;
@@ -442,8 +457,13 @@ __global__ void __launch_bounds__(256) k_front_fast(const uint8_t* __restrict__ 
         // pointer (the per-chunk range tests of ffast_chunk were an eighth of this kernel's vector instructions)
         if (first_al >= 0 && first_al + 8L * 2048 <= n) {       // (block-uniform)
             const uint4* p = (const uint4*)(base + first_al) + (512 * wave + lane);
+            if (nt_loads) {                                     // (launch-uniform) a batch that no cache can hold: see front_fused()
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[64 * u];
+                for (int u = 0; u < 8; ++u) v[u] = ld_stream16(p + 64 * u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[64 * u];
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = ffast_chunk(base, first_al + 8L * (512 * wave + lane + 64 * u), n);
@@ -1161,7 +1181,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
                 const double t = xq - j0f;
                 const cplx v0 = buf1[j0], v1 = buf1[j1];
                 const cplx v = make_double2(v0.x + t * (v1.x - v0.x), v0.y + t * (v1.y - v0.y));
-                dst[i] = cmul(v, cmul(SA4[i >> 5], T4[36 + (i & 31)]));
+                st_stream16(dst + i, cmul(v, cmul(SA4[i >> 5], T4[36 + (i & 31)])));
             }
         }
         __syncthreads();                                        // buf1 (= xs) and the tables' S slot may be rewritten
@@ -1396,7 +1416,7 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (a.dst_stream_stride < 0) dst[i] = cmul(v, cmul(SA4[i >> 5], b4));
                 else buf0[i] = cmul(v, cmul(SA4[i >> 5], b4));
 #else
-                dst[i] = cmul(v, cmul(SA4[i >> 5], b4));
+                st_stream16(dst + i, cmul(v, cmul(SA4[i >> 5], b4)));
 #endif
             }
         }
