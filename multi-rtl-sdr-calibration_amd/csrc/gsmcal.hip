@@ -97,6 +97,8 @@ struct gsmcal_ctx {
     size_t call_raw_bytes = 0;      // raw bytes of the batch call in progress
     int snr_inline_pipe = 1;        // GSMCAL_SNR_INLINE_PIPE=0: the two-kernel detector in the scanner's pipeline stages (the inline form is used there
                                     // only while a stage's workgroups are all resident at once: 3 per CU)
+    int scan_split = 88;            // GSMCAL_SCAN_SPLIT: percent of a pipeline stage's captures in the first of its two front-kernel launches (0: one launch;
+                                    // 12 800 captures: 0 / 70 / 80 / 88 / 94 -> 3.64 / 3.58 / 3.525 / 3.515 / 3.57 ms)
     int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
@@ -653,17 +655,21 @@ static const auto k_coarse_scan_gen = &k_coarse_scan<2, false>;
 static const auto k_coarse_scan_ref = &k_coarse_scan<3, true, true>;   // the drivers' window geometry as constants
 static const auto k_coarse_scan_inl = &k_coarse_scan<3, true, true, true>;   // ... with the window SNRs computed in place (throughput batches)
 
+// (s_off, S_all: streams [s_off, s_off + S) of a lane that holds S_all -- the scanner pipeline launches a stage's front kernel in two parts)
 int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double* d_coef, int ntaps, int decim,
-                cplx* d_out, long out_stride) {
+                cplx* d_out, long out_stride, int s_off = 0, int S_all = 0) {
+    if (S_all < S + s_off) S_all = S + s_off;
     const long nd = (n + decim - 1) / decim;
     const size_t span = (size_t)256 * decim + ntaps + 24;
     const size_t lds = (size_t)((ntaps * 8 + 15) & ~15) + (span + span / 8 + 16) * 2;
     if (lds > 159 * 1024) return GSMCAL_E_UNSUPPORTED;
     const unsigned nblk = (unsigned)((nd + 255) / 256);
-    RET_IF(ensure(c, c->cur->state, (size_t)S * sizeof(StreamState)));
-    RET_IF(ensure(c, c->cur->partial, (size_t)S * nblk * 4 * 2 * sizeof(unsigned long long)));
+    RET_IF(ensure(c, c->cur->state, (size_t)S_all * sizeof(StreamState)));
+    RET_IF(ensure(c, c->cur->partial, (size_t)S_all * nblk * 4 * 2 * sizeof(unsigned long long)));
     c->cur->npartial = (int)nblk;
-    c->last_S = S;
+    c->last_S = S_all;
+    d_raw += (size_t)s_off * 2 * n;
+    d_out += (size_t)s_off * out_stride;
     bool sym = (int)c->h_coef.size() == ntaps;                 // linear-phase taps? (fir1 and the .fda designs are)
     for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
     if ((ntaps == 47 || ntaps == 31) && decim == 64 && ((uintptr_t)d_raw & 15) == 0 && ((2 * n) & 15) == 0 &&
@@ -677,12 +683,12 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
         // Infinity Cache from the second step on and keeps plain loads: there nt costs 1 us of 22.6 / 4 us of 88.
         // GSMCAL_FRONT_NT=0/1 overrides.
         const int nt = c->front_nt >= 0 ? c->front_nt : (c->call_raw_bytes > ((size_t)256 << 20) ? 1 : 0);
-#define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef, nd, d_out, out_stride, nt)
+#define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p + (size_t)s_off * nblk * 4 * 2, d_coef, nd, d_out, out_stride, nt)
         if (ntaps == 47) { if (sym) FRONT_FAST(k_front_fast47_sym); else FRONT_FAST(k_front_fast47); }
         else { if (sym) FRONT_FAST(k_front_fast31_sym); else FRONT_FAST(k_front_fast31); }
 #undef FRONT_FAST
     } else {
-        LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p, d_coef,
+        LAUNCH(c, k_front_fused, dim3(nblk, S), dim3(256), lds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p + (size_t)s_off * nblk * 2, d_coef,
                ntaps, decim, nd, d_out, out_stride, sym ? 1 : 0);
     }
     CHECK_LAUNCH(c);
@@ -1058,6 +1064,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_MIN")) c->snr_inline_min = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_KEEP")) c->snr_inline_keep = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_FRONT_NT")) c->front_nt = atoi(e2);
+    if (const char* e2 = getenv("GSMCAL_SCAN_SPLIT")) c->scan_split = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_PIPE")) c->snr_inline_pipe = atoi(e2);
     const char* sst = getenv("GSMCAL_SCAN_STAGES");
     if (sst && atoi(sst) >= 1) c->scan_stages = atoi(sst);
@@ -1629,8 +1636,13 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             if (!L.front_done) HIPCHK(c, hipEventCreateWithFlags(&L.front_done, hipEventDisableTiming));
             if (i > 0) HIPCHK(c, hipStreamWaitEvent(L.stream, c->lanes[i - 1].front_done, 0));
         }
-        RET_IF(front_fused(c, raw_i, S, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
+        // The next stage's front kernel waits for this one through an event, and that hand-over leaves the memory system idle for
+        // ~12 us per stage (rocprofv3 timeline).  So the stage's front kernel is launched in two parts: the event sits behind the
+        // first (GSMCAL_SCAN_SPLIT percent of the captures), and the rest runs on this lane underneath the start of the next stage.
+        const int S_a = nl > 1 && i + 1 < nl && c->scan_split > 0 && c->scan_split < 100 ? std::max(1, (int)((long)S * c->scan_split / 100)) : S;
+        RET_IF(front_fused(c, raw_i, S_a, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd, 0, S));
         if (nl > 1) HIPCHK(c, hipEventRecord(L.front_done, L.stream));
+        if (S_a < S) RET_IF(front_fused(c, raw_i, S - S_a, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd, S_a, S));
         // the acceptance rule (multi_rtl_sdr_gsm_FCCH_scanner.m:168-185) runs at the end of k_coarse_scan, on the state it just built
         ScanAccept acc;
         acc.snr_numhit = d_snr_numhit + (size_t)2 * lo;

@@ -5,6 +5,7 @@
     python profiles/rocpd_summary.py pmc    <fetch.db> <write.db> <out.json> <streams> <samples_per_stream>
     python profiles/rocpd_summary.py sq     <sq.db> <out.csv>
     python profiles/rocpd_summary.py valu   <out.json> <regime>=<sq.db>:<launches per step> ...
+    python profiles/rocpd_summary.py timeline <results.db> <out.csv> <last_n_dispatches>
 
 stats: per-kernel launch count, total / average / min / max duration (ns) -- the `--kernel-trace --stats` table.
 sq:    per-kernel means of every counter of an SQ pass (rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
@@ -39,6 +40,17 @@ def stats(db, out, skip=0):
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1][skip:])):
             v = v[skip:] or v
             w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / tot_all, 2), min(v), max(v)])
+
+
+def timeline(db, out, last_n):
+    """start / end (us, relative to the first listed) of the last `last_n` kernel dispatches: who overlaps whom"""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()[-last_n:]
+    t0 = rows[0][1]
+    with open(out, "w") as f:
+        f.write("kernel,start_us,end_us,duration_us\n")
+        for name, s_, e_ in rows:
+            f.write(f"{short(name)},{(s_ - t0) / 1e3:.1f},{(e_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f}\n")
 
 
 def pmc_table(db, counter):
@@ -128,7 +140,9 @@ def valu(out, specs):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "valu":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == "valu":
         valu(sys.argv[2], sys.argv[3:])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
