@@ -4,7 +4,7 @@
     python profiles/rocpd_summary.py stats  <results.db> <out.csv> [skip_first_n_per_kernel]
     python profiles/rocpd_summary.py pmc    <fetch.db> <write.db> <out.json> <streams> <samples_per_stream>
     python profiles/rocpd_summary.py sq     <sq.db> <out.csv>
-    python profiles/rocpd_summary.py valu   <out.json> <regime>=<sq.db>:<launches per step> ...
+    python profiles/rocpd_summary.py valu   <out.json> <regime>=<sq.db>:<launches per step | sN = N steps profiled in all> ...
     python profiles/rocpd_summary.py timeline <results.db> <out.csv> <last_n_dispatches>
 
 stats: per-kernel launch count, total / average / min / max duration (ns) -- the `--kernel-trace --stats` table.
@@ -120,6 +120,9 @@ def valu(out, specs):
     for spec in specs:
         regime, rest = spec.split("=", 1)
         db, lps = rest.rsplit(":", 1)
+        nsteps = 0
+        if lps.startswith("s"):                      # ":s8" = the profiled command ran 8 steps in all (kernels launched in different sizes within a step)
+            nsteps, lps = int(lps[1:]), 0
         lps = int(lps)
         cur = sqlite3.connect(db).cursor()
         cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -133,8 +136,13 @@ def valu(out, specs):
                 continue
             per.setdefault(short(name), {}).setdefault(did, 0.0)
             per[short(name)][did] += float(val)
-        det = {k: int(round(sum(v.values()) / len(v) * lps)) for k, v in per.items() if len(v) >= 4}
-        res[regime] = {"valu_wave_instr_per_step": int(sum(det.values())), "per_kernel": det, "launches_per_step_per_kernel": lps}
+        if nsteps:
+            det = {k: int(round(sum(v.values()) / nsteps)) for k, v in per.items() if len(v) >= 4}
+            res[regime] = {"valu_wave_instr_per_step": int(sum(det.values())), "per_kernel": det, "steps_profiled": nsteps,
+                           "launches_per_kernel": {k: len(v) for k, v in per.items() if len(v) >= 4}}
+        else:
+            det = {k: int(round(sum(v.values()) / len(v) * lps)) for k, v in per.items() if len(v) >= 4}
+            res[regime] = {"valu_wave_instr_per_step": int(sum(det.values())), "per_kernel": det, "launches_per_step_per_kernel": lps}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
 
