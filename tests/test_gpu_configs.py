@@ -203,3 +203,54 @@ def test_bench_distributed_step_on_one_rank_and_its_fall_back(fail_native):
         assert "GSMCAL_BENCH_FAIL_NATIVE" in cfg["collective_fallback_from_native"]
     else:
         assert "native RCCL" in cfg["collective"] and "collective_fallback_from_native" not in cfg
+
+
+@pytest.mark.parametrize("n_samples", [250000, 250003])
+def test_scanner_pipeline_choices_change_no_bit(g_mod, ctx, monkeypatch, n_samples):
+    """A scanner batch big enough for the pipeline (2 100 captures: 8 stages) through every way the library can schedule it --
+    stages with the front kernel launched in two parts and the detector computing its SNRs in place (the default), one stage,
+    stages with the two-kernel detector and unsplit front kernels, plain instead of non-temporal raw loads -- must give the same
+    bits; sampled captures against the oracle.  250 003 samples: no capture after the first starts on a 16-byte boundary, so the
+    any-geometry front kernel runs (its partial sums are addressed through the same per-part offsets)."""
+    g = g_mod
+    D, K, n = 2100, 8, n_samples
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)
+    base = np.stack([g.synth.make_stream(dongle=7100, arfcn=i, num_frames=26, bcch=i % 4 != 3,
+                                         **({"snr_db": 5.0 + i} if i % 4 == 1 else {}))[0][: 2 * n] for i in range(K)])
+    H = g.MAX_HITS
+    d_base, d_raw = ctx.alloc(base.nbytes), ctx.alloc(D * 2 * n)
+    d_out, d_pos, d_psn, d_cnt = ctx.alloc(D * 16), ctx.alloc(D * H * 8), ctx.alloc(D * H * 8), ctx.alloc(D * 4)
+    variants = {"default": {}, "one_stage": {"GSMCAL_SCAN_STAGES": "1"},
+                "two_kernel_detector_unsplit": {"GSMCAL_SNR_INLINE_PIPE": "0", "GSMCAL_SCAN_SPLIT": "0"},
+                "plain_loads_12_stages": {"GSMCAL_FRONT_NT": "0", "GSMCAL_SCAN_STAGES": "12"}}
+    made = {}
+    try:
+        ctx.h2d(d_base, base)
+        g.synth_expand_dev(d_base, K, n, d_raw, D, first_unit=0, ctx=ctx)
+        ctx.sync()
+        outs = {}
+        for name, env in variants.items():
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            made[name] = cx = g.Context(0)
+            for k in env:
+                monkeypatch.delenv(k)
+            for rep in range(3):                                      # eager, captured, replayed
+                g.fcch_scan_batch_dev(d_raw, D, n, coef, d_out, d_pos, d_psn, d_cnt, ctx=cx)
+            cx.sync()
+            sn = np.empty((D, 2)); ps = np.empty((D, H)); pn = np.empty((D, H)); cn = np.empty(D, dtype=np.int32)
+            cx.d2h(sn, d_out); cx.d2h(ps, d_pos); cx.d2h(pn, d_psn); cx.d2h(cn, d_cnt)
+            outs[name] = (sn, ps, pn, cn)
+        ref = outs["default"]
+        for name, o_ in outs.items():
+            for a, b in zip(ref, o_):
+                assert np.array_equal(a, b, equal_nan=True), name
+        rng = np.random.default_rng(11)
+        units = sorted(set([0, 1, D - 1] + [int(x) for x in rng.integers(0, D, 13)]))
+        _check_units(g, base, units, *ref, coef)
+        assert np.sum(ref[3] > 0) > D // 4 and np.sum(ref[0][:, 1] > 0) > 0      # (26-frame captures: few reach the acceptance rule's hit count)
+    finally:
+        for cx in made.values():
+            cx.close()
+        for p_ in (d_base, d_raw, d_out, d_pos, d_psn, d_cnt):
+            ctx.free(p_)
