@@ -853,9 +853,10 @@ int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
     // kernels in each other's way (measured: 1 lane 6.30 ms, 2 lanes 7.43 ms for 12,800 captures), so big scanner
     // batches are cut into pipeline stages instead: the front kernels run one after the other (chained by events) and
     // each stage's detector runs underneath the next stage's front kernel.
-    // Stage size: about 550 captures (at least 8 stages) -- a stage of at most 3 x 256 captures lets its detector run as ONE
-    // resident round of k_coarse_scan<INL> workgroups (12 800 captures: 16 / 24 / 32 stages 3.75 / 3.69 / 3.71 ms).
-    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 2048 ? std::max(8, (d + 549) / 550) : 1));
+    // Stage size: at most 640 captures (at least 8 stages) -- a stage of at most 3 x 256 captures lets its detector run as ONE
+    // resident round of k_coarse_scan<INL> workgroups (12 800 captures, with the split front launches: 16 two-kernel / 20 / 24 /
+    // 32 stages 3.69 / 3.50 / 3.56 / 3.56 ms).
+    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 2048 ? std::max(8, (d + 639) / 640) : 1));
     if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;
