@@ -203,8 +203,17 @@ class Calib:
         return self.host_table[b] if self.zero_copy else self.table_t[b].cpu()
 
 
-def time_steps(torch, dev, fn, steps, warmup, fence=None):
+SUB_PREWARM_S = 0.06       # sub-results (single rank): the same step repeated for this long before their warm-up steps -- see --prewarm-steps
+
+
+def time_steps(torch, dev, fn, steps, warmup, fence=None, prewarm_s=0.0):
     fence = fence or (lambda: torch.cuda.synchronize(dev))
+    if prewarm_s > 0.0:                                     # (clock / power state: a sub-result starts after host-side work too)
+        t_end = time.perf_counter() + prewarm_s
+        while time.perf_counter() < t_end:
+            for _ in range(4):
+                fn()
+            fence()
     for _ in range(warmup):
         fn()
     fence()
@@ -592,7 +601,7 @@ def time_calib(torch, gsmcal, dev, ctx, raw_t, N, coef, ts, fc, K, W):
     def st():
         c2.launch(0)
         c2.to_host(0)
-    t = time_steps(torch, dev, st, K, W) / K
+    t = time_steps(torch, dev, st, K, W, prewarm_s=SUB_PREWARM_S) / K
     torch.cuda.synchronize(dev)
     return t, c2.table(0).numpy().copy(), c2
 
@@ -681,7 +690,7 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         def two():
             cal.launch(0, 2)
             cal.to_host(0)
-        t = time_steps(torch, dev, two, K, W) / K
+        t = time_steps(torch, dev, two, K, W, prewarm_s=SUB_PREWARM_S) / K
         sub["config2_two_streams"] = {"streams": 2, "ms_per_call": round(1e3 * t, 4), "Msample_per_s": round(2 * N / t / 1e6, 1)}
         cal.launch(0)
         torch.cuda.synchronize(dev)
@@ -697,7 +706,7 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
                 kk[0] += 1
                 c_.launch(0)
                 c_.to_host(0)
-            t = time_steps(torch, dev, rot, K, W + 4) / K
+            t = time_steps(torch, dev, rot, K, W + 4, prewarm_s=SUB_PREWARM_S) / K
             same = all(np.array_equal(c_.table(0).numpy(), cals[0].table(0).numpy(), equal_nan=True) for c_ in cals[1:])
             v = cal.D * N / t / 1e6
             sub["input_rotated_over_4_buffers"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
@@ -720,7 +729,7 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         def st():
             cs.launch(0)
             cs.to_host(0)
-        t = time_steps(torch, dev, st, max(3, K // 4), 2) / max(3, K // 4)
+        t = time_steps(torch, dev, st, max(3, K // 4), 2, prewarm_s=SUB_PREWARM_S) / max(3, K // 4)
         v = cal.D * N / t / 1e6
         sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
                               "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
@@ -800,7 +809,7 @@ def bench_two_in_flight(args, torch, gsmcal, dev, cal, coef, ts, fc, N):
             cals[i].launch(0)
             cals[i].to_host(0)
     try:
-        t = time_steps(torch, dev, step, 2 * args.steps, 4) / (2 * args.steps)
+        t = time_steps(torch, dev, step, 2 * args.steps, 4, prewarm_s=SUB_PREWARM_S) / (2 * args.steps)
         torch.cuda.synchronize(dev)
         ok = bool(torch.equal(cals[0].table(0), cal.table(0)) or torch.allclose(cals[0].table(0), cal.table(0), equal_nan=True))
     finally:
@@ -887,7 +896,7 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    elapsed = time_steps(torch, dev, step, steps, warmup, fence)
+    elapsed = time_steps(torch, dev, step, steps, warmup, fence, prewarm_s=0.0 if use_dist else SUB_PREWARM_S)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -2,7 +2,7 @@ mkdir -p gpurun_out
 O=gpurun_out/r04_s21.txt
 : > $O
 for rep in 1 2; do
-for L in libgsmcal.so exp_t744.so; do
+for L in libgsmcal.so exp_stnt.so; do
 echo "$L: $(GSMCAL_LIB=$PWD/multi-rtl-sdr-calibration_amd/lib/$L python bench.py --mode stream --steps 20 --warmup 3 --no-cpu-baseline --no-sub --cache-streams /tmp/ab_streams.npy 2>>gpurun_out/r04_s21.err | python -c "
 import sys, json
 for l in sys.stdin:
