@@ -1213,7 +1213,7 @@ __host__ __device__ constexpr size_t st47_xs_n(int tile) { return (size_t)(tile 
 __host__ __device__ constexpr size_t st47_buf_n(int tile) { return (size_t)tile + 8 + 4; }
 __host__ __device__ inline size_t stream_tile_s47_lds(int tile = ST47_TILE) {
     const size_t xs_n = st47_xs_n(tile), buf = st47_buf_n(tile);
-    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + 2 * (68 + 34) * sizeof(cplx);
+    return (buf + (xs_n > buf ? xs_n : buf)) * sizeof(cplx) + 2 * 68 * sizeof(cplx);
 }
 // four consecutive outputs i0 .. i0+3 (i0 a multiple of 4) of the 47-tap symmetric filter from the padded copy xq; c[t] = coef[t], t < 24
 template <int S0, int G>
@@ -1264,7 +1264,7 @@ __device__ __forceinline__ void fir4_sym47(const cplx* __restrict__ xq, const do
 // this kernel's instructions), and the two accurate sincos per tile cost the wave that holds their lanes another ~200
 struct StTile { long lo0, lo2, lo3, first, first_al; int cnt0, cnt2, L4, nchunk; };
 template <int TILE>
-__global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(3, ST47_MAXW))) k_stream_tile_s47(const StreamState* __restrict__ sts, StreamTileArgs a) {
+__global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(4, ST47_MAXW))) k_stream_tile_s47(const StreamState* __restrict__ sts, StreamTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ StTile tl[ST_TPB];
     __shared__ cplx S2[ST_TPB], S4[ST_TPB];                     // exp(1i*fl(k0*c)) per tile and derotation
@@ -1291,8 +1291,6 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
     cplx* xs = buf1;
     cplx* T2 = buf1 + (xs_n > bufn ? xs_n : bufn);              // T[2..35] = A[0..33], T[36..67] = B[0..31] (k_stream_tile's layout)
     cplx* T4 = T2 + 68;
-    cplx* SA2 = T4 + 68;
-    cplx* SA4 = SA2 + 34;
     const unsigned short* base = (const unsigned short*)(a.raw + (size_t)s * a.raw_stride);
     double cf[24];                                              // the taps (uniform addresses: scalar loads)
 #pragma unroll
@@ -1329,6 +1327,18 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     // B[m] of a lane's samples: i = tid + 256 k, so i & 31 = tid & 31 for every k -- one read per workgroup instead of one per sample
     const cplx b2 = T2[36 + (tid & 31)], b4 = T4[36 + (tid & 31)];
+    // ... and so is A[i >> 5] for the lane's k-th sample of a pass, (tid >> 5) + 8 k: the products A*B of the lane's (up to) four
+    // samples per pass live in registers for the whole workgroup, and a sample's rotator is S(tile) * (A*B) -- one product per
+    // sample, no per-tile S*A table in LDS and no read of it per sample (stream mode 0.608 -> 0.594 ms).  (S*(A*B) instead of
+    // (S*A)*B: the same three factors, associated the other way -- a relative difference of 1e-16 against the general kernel's
+    // rotator.)  128 registers: still four waves per SIMD.
+    static_assert(TILE + 8 <= 4 * ST_THREADS, "a pass is at most four samples per lane");
+    cplx ab2[4], ab4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ab2[k] = cmul(T2[2 + (tid >> 5) + 8 * k], b2);
+        ab4[k] = cmul(T4[2 + (tid >> 5) + 8 * k], b4);
+    }
     // the first tile's raw bytes: chunk `tid` (8 samples, 16-byte aligned) of [first_al, first + span)
     uint4 pre = make_uint4(0u, 0u, 0u, 0u);
     if (tid < tl[0].nchunk) pre = ffast_chunk(base, tl[0].first_al + 8L * tid, n0);
@@ -1362,13 +1372,8 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
             }
         }
-        // S * A[q] of this tile for both derotations (34 + 34 products): a sample's rotator is then one product, SA[m>>5]*B[m&31] --
-        // the same three factors as st_rot(), associated the same way ((S*A)*B), bit-identical
-        if (tid >= 128 && tid < 128 + 68) {
-            const int q = (tid - 128) % 34, which = (tid - 128) / 34;
-            (which ? SA4 : SA2)[q] = cmul((which ? S4 : S2)[t], (which ? T4 : T2)[2 + q]);
-        }
-        __syncthreads();                                        // xs and SA complete
+        const cplx s2t = S2[t], s4t = S4[t];                    // the tile's S rotators (uniform reads)
+        __syncthreads();                                        // xs complete
         // ---- the next tile's raw chunk: requested now, it lands under the FIR ----
         pre = make_uint4(0u, 0u, 0u, 0u);
         if (t + 1 < ntl && tid < tl[t + 1].nchunk) pre = ffast_chunk(base, tl[t + 1].first_al + 8L * tid, n0);
@@ -1387,15 +1392,19 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
         {
             const double dlo2 = (double)lo2, dlo0 = (double)lo0;
             const int last0 = cnt0 - 1;
-            for (int i = tid; i < cnt2; i += ST_THREADS) {
-                const double xq = (dlo2 + (double)i) * f1;
-                const double j0f = floor(xq);
-                const int j0 = (int)(j0f - dlo0);
-                const int j1 = j0 + 1 > last0 ? last0 : j0 + 1;
-                const double tt = xq - j0f;
-                const cplx v0 = buf0[j0], v1 = buf0[j1];
-                const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
-                buf1[i] = cmul(v, cmul(SA2[i >> 5], b2));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                       // (cnt2 <= 4 * ST_THREADS: static register indices for ab2)
+                const int i = tid + k * ST_THREADS;
+                if (i < cnt2) {
+                    const double xq = (dlo2 + (double)i) * f1;
+                    const double j0f = floor(xq);
+                    const int j0 = (int)(j0f - dlo0);
+                    const int j1 = j0 + 1 > last0 ? last0 : j0 + 1;
+                    const double tt = xq - j0f;
+                    const cplx v0 = buf0[j0], v1 = buf0[j1];
+                    const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
+                    buf1[i] = cmul(v, cmul(s2t, ab2[k]));
+                }
             }
         }
         __syncthreads();
@@ -1404,23 +1413,22 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
         {
             const double dlo3 = (double)lo3, dlo2 = (double)lo2;
             const int last2 = cnt2 - 1;
-            for (int i = tid; i < L4; i += ST_THREADS) {
-                const double xq = (dlo3 + (double)i) * f3;
-                const double j0f = floor(xq);
-                const int j0 = (int)(j0f - dlo2);
-                const int j1 = j0 + 1 > last2 ? last2 : j0 + 1;
-                const double tt = xq - j0f;
-                const cplx v0 = buf1[j0], v1 = buf1[j1];
-                const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
-#ifdef GSMCAL_EXP_NOSTORE      /* development experiment: the kernel without its 16 B/sample of output traffic */
-                if (a.dst_stream_stride < 0) dst[i] = cmul(v, cmul(SA4[i >> 5], b4));
-                else buf0[i] = cmul(v, cmul(SA4[i >> 5], b4));
-#else
-                st_stream16(dst + i, cmul(v, cmul(SA4[i >> 5], b4)));
-#endif
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + k * ST_THREADS;
+                if (i < L4) {
+                    const double xq = (dlo3 + (double)i) * f3;
+                    const double j0f = floor(xq);
+                    const int j0 = (int)(j0f - dlo2);
+                    const int j1 = j0 + 1 > last2 ? last2 : j0 + 1;
+                    const double tt = xq - j0f;
+                    const cplx v0 = buf1[j0], v1 = buf1[j1];
+                    const cplx v = make_double2(v0.x + tt * (v1.x - v0.x), v0.y + tt * (v1.y - v0.y));
+                    st_stream16(dst + i, cmul(v, cmul(s4t, ab4[k])));
+                }
             }
         }
-        __syncthreads();                                        // buf1 (= xs) and SA may be rewritten
+        __syncthreads();                                        // buf1 (= xs) may be rewritten
     }
 }
 

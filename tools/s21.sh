@@ -2,7 +2,7 @@ mkdir -p gpurun_out
 O=gpurun_out/r04_s21.txt
 : > $O
 for rep in 1 2; do
-for L in libgsmcal.so exp_stnt.so; do
+for L in exp_prev.so libgsmcal.so; do
 echo "$L: $(GSMCAL_LIB=$PWD/multi-rtl-sdr-calibration_amd/lib/$L python bench.py --mode stream --steps 20 --warmup 3 --no-cpu-baseline --no-sub --cache-streams /tmp/ab_streams.npy 2>>gpurun_out/r04_s21.err | python -c "
 import sys, json
 for l in sys.stdin:
@@ -12,3 +12,4 @@ for l in sys.stdin:
 ")" >> $O
 done; done
 cat $O
+python -m pytest tests -m gpu -q -p no:cacheprovider -x -k "stream" 2>&1 | tail -3

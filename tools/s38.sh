@@ -1,0 +1,15 @@
+mkdir -p gpurun_out
+O=gpurun_out/r04_s38.txt
+: > $O
+for rep in 1 2; do
+for r in 0 1; do
+echo "rounds $r: $(GSMCAL_STREAM_ROUNDS=$r python bench.py --mode stream --steps 20 --warmup 3 --no-cpu-baseline --no-sub --cache-streams /tmp/ab_streams.npy 2>>gpurun_out/r04_s38.err | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); k = d.get('kernels_ms_per_step_untimed_pass') or {}
+        print(d['ms_per_step'], d['roofline']['frac'], ' '.join('%s=%.1f' % (a.strip('()').split('<')[0][2:], 1e3 * b) for a, b in list(k.items())[:2]))
+")" >> $O
+done; done
+cat $O
+python -m pytest tests -m gpu -q -p no:cacheprovider -x -k "stream or r_correct or want_r or equalise" 2>&1 | tail -3
