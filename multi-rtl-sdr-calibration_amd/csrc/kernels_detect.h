@@ -1832,10 +1832,14 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                     // the usual chunk: all eight samples inside the span and the stream -- no per-sample tests, and two
                     // 16-byte-aligned groups of four padded slots (i_base is a multiple of 8 here only when first is aligned, so
                     // the stores stay per sample; the tests were most of this loop)
+                    // (xs_pad(i_base + u) = xs_pad(i_base) + u + ((r + u) >> 2), r = i_base & 3 the same in every lane: one lane
+                    // address plus scalar offsets, as in k_stream_tile_s47)
+                    const int r = __builtin_amdgcn_readfirstlane(i_base & 3);
+                    cplx* xp = xq + xs_pad(i_base);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const unsigned q = wv[u >> 1] >> (16 * (u & 1));
-                        xq[xs_pad(i_base + u)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
+                        xp[u + ((r + u) >> 2)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
                     }
                 } else {
 #pragma unroll

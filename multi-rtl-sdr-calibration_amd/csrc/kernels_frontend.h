@@ -1354,10 +1354,14 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
                 const long g_base = first + i_base;
                 const unsigned wv[4] = {pre.x, pre.y, pre.z, pre.w};
                 if (i_base >= 0 && i_base + 8 <= span && g_base >= 0 && g_base + 8 <= n0) {
+                    // xs_pad(i_base + u) = xs_pad(i_base) + u + ((r + u) >> 2) with r = i_base & 3 = (-off) & 3, the same in every
+                    // lane: the eight slots are one lane address plus scalar offsets (three vector instructions per slot before)
+                    const int r = __builtin_amdgcn_readfirstlane((-off) & 3);
+                    cplx* xp = xs + xs_pad(i_base);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const unsigned q = wv[u >> 1] >> (16 * (u & 1));
-                        xs[xs_pad(i_base + u)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
+                        xp[u + ((r + u) >> 2)] = make_double2((double)(q & 0xFFu) - mr, (double)((q >> 8) & 0xFFu) - mi);
                     }
                 } else {
 #pragma unroll
@@ -1390,13 +1394,13 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
         __syncthreads();                                        // (xs is dead: buf1 may be written)
         // ---- pass 2: level 1 = interp1 (FCCH_fine_correction.m:123-125), level 2 = .* exp(1i*k*c2) (:165) -> buf1 ----
         {
-            const double dlo2 = (double)lo2, dlo0 = (double)lo0;
+            const double dlo0 = (double)lo0, p2 = (double)lo2 + (double)tid;   // (integers below 2^53: every sum here is exact)
             const int last0 = cnt0 - 1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                       // (cnt2 <= 4 * ST_THREADS: static register indices for ab2)
                 const int i = tid + k * ST_THREADS;
                 if (i < cnt2) {
-                    const double xq = (dlo2 + (double)i) * f1;
+                    const double xq = (p2 + (double)(k * ST_THREADS)) * f1;
                     const double j0f = floor(xq);
                     const int j0 = (int)(j0f - dlo0);
                     const int j1 = j0 + 1 > last0 ? last0 : j0 + 1;
@@ -1411,13 +1415,13 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
         // ---- pass 3: level 3 = interp1 (SCH_corr_rate_correction.m:126-127), level 4 = .* exp(1i*k*c4) (carrier_correct_post_SCH.m:83) ----
         cplx* dst = a.dst + (size_t)s * a.dst_stream_stride + lo3;
         {
-            const double dlo3 = (double)lo3, dlo2 = (double)lo2;
+            const double dlo2 = (double)lo2, p3 = (double)lo3 + (double)tid;
             const int last2 = cnt2 - 1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = tid + k * ST_THREADS;
                 if (i < L4) {
-                    const double xq = (dlo3 + (double)i) * f3;
+                    const double xq = (p3 + (double)(k * ST_THREADS)) * f3;
                     const double j0f = floor(xq);
                     const int j0 = (int)(j0f - dlo2);
                     const int j1 = j0 + 1 > last2 ? last2 : j0 + 1;
