@@ -1202,9 +1202,11 @@ __global__ void __launch_bounds__(ST_THREADS) k_stream_tile(const StreamState* _
 // Passes 2 and 3 (lerp x rotator) are k_stream_tile's.  grid (ceil(N / (ST_TILE * ST_TPB)), S), block 256.
 // ------------------------------------------------------------------------------------------------
 // TILE: level-4 samples per tile; TILE + 8 level-0 samples are filtered per tile (the two lerps stretch a tile by < 8).  1016
-// (one FIR round of 256 x 4, 42.5 KB of LDS: three workgroups per CU) or 952 (240 x 4, 40 KB: four per CU)
+// (one FIR round of 256 x 4: three workgroups per CU, 0.592 against 0.566 ms) or the largest that still leaves four per CU: 952
+// (240 x 4) while the per-tile S*A tables took another kilobyte, 1000 (252 x 4, 40 512 B with the static part) since they are
+// gone -- stream mode 0.593 -> 0.589 ms (1008: the same; 744 with five workgroups per CU: slower)
 #ifndef ST47_TILE
-#define ST47_TILE 952
+#define ST47_TILE 1000
 #endif
 #ifndef ST47_MAXW
 #define ST47_MAXW 4           /* waves per SIMD the register allocation leaves room for */

@@ -509,7 +509,7 @@ def test_window_snrs_computed_inside_the_scan_kernel_are_the_table_kernels(g, se
 
 
 def test_stream_mode_kernels_agree_to_rounding_and_with_the_oracle_on_unaligned_captures(g, setup, monkeypatch):
-    """r_correct from k_stream_tile_s47 (the drivers' 47 symmetric taps: taps in registers, 952-sample tiles) and from the general
+    """r_correct from k_stream_tile_s47 (the drivers' 47 symmetric taps: taps in registers, 1000-sample tiles) and from the general
     k_stream_tile (GSMCAL_STREAM_S47=0, 1016-sample tiles): the same filter sums in the same order; the rotators
     exp(1i*k*c) = S*A*B are factored per TILE (S = exp(1i*fl(k0*c)) with the tile's first index k0), so the two tilings differ by
     the rounding of the three ARGUMENTS -- up to 2 ulp(k*c) ~ 1e-11 rad at k ~ 6e5, the accuracy DESIGN.md states for the
