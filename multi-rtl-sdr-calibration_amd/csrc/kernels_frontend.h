@@ -1384,6 +1384,10 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
         pre = make_uint4(0u, 0u, 0u, 0u);
         if (t + 1 < ntl && tid < tl[t + 1].nchunk) pre = ffast_chunk(base, tl[t + 1].first_al + 8L * tid, n0);
         // ---- pass 1: filter(coef,1,.) -> buf0 ----
+        // (issue priority: the filter pass is a long run of independent FMAs, the other phases are short dependent chains behind LDS
+        // round trips -- waves in those phases issue first, the filter passes of the CU's other workgroups fill the rest:
+        // stream mode 0.585 -> 0.578 ms; the other way round 0.594)
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
         for (int i0 = 4 * tid; i0 < cnt0; i0 += 4 * ST_THREADS) {
             cplx y[4];
@@ -1393,6 +1397,7 @@ __global__ void __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu
             // fifty samples alive across them: 200 registers and a scratch frame)
             buf0[i0] = y[0]; buf0[i0 + 1] = y[1]; buf0[i0 + 2] = y[2]; buf0[i0 + 3] = y[3];
         }
+        __builtin_amdgcn_s_setprio(2);
         __syncthreads();                                        // (xs is dead: buf1 may be written)
         // ---- pass 2: level 1 = interp1 (FCCH_fine_correction.m:123-125), level 2 = .* exp(1i*k*c2) (:165) -> buf1 ----
         {
