@@ -855,8 +855,9 @@ int plan_lanes(gsmcal_ctx* c, int d, bool latency_bound = true) {
     // each stage's detector runs underneath the next stage's front kernel.
     // Stage size: at most 640 captures (at least 8 stages) -- a stage of at most 3 x 256 captures lets its detector run as ONE
     // resident round of k_coarse_scan<INL> workgroups (12 800 captures, with the split front launches: 16 two-kernel / 20 / 24 /
-    // 32 stages 3.69 / 3.50 / 3.56 / 3.56 ms).
-    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 2048 ? std::max(8, (d + 639) / 640) : 1));
+    // 32 stages 3.69 / 3.50 / 3.56 / 3.56 ms).  From 1 200 captures on four stages already pay (1 600 captures: 1 / 2 / 3 / 4 stages
+    // 0.547 / 0.510 / 0.585 / 0.504 ms; 800: 0.269 / 0.268 / 0.334 / 0.274; 400: 0.146 / 0.163 / 0.217 / 0.194).
+    int nl = latency_bound ? c->n_lanes_cfg : (c->scan_stages > 0 ? c->scan_stages : (d >= 1200 ? std::max(d >= 2048 ? 8 : 4, (d + 639) / 640) : 1));
     if (latency_bound && nl > d / c->lane_min) nl = d / c->lane_min;   // a minimum of streams per lane: below that splitting only adds launches
     if (nl > MAX_LANES) nl = MAX_LANES;
     if (nl < 1) nl = 1;
