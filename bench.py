@@ -420,6 +420,29 @@ def main():
     for _ in range(args.prewarm_steps):
         step()
     fence()
+    # N > 1, native collective, no explicit choice: where the all-gather sits is decided by measurement during the warm-up -- in
+    # line on the chain's stream (costs RCCL's small-message latency per step: 1.6 us on one rank, unknown over xGMI) or on the
+    # library's side stream behind an event (costs ~14 us per step on one rank, hides the collective under the next step).  Both
+    # timed over 40 steps, max over ranks, every rank takes the same decision.
+    autotune = None
+    if use_dist and gather_kind == "native" and "GSMCAL_BENCH_GATHER" not in os.environ:
+        def trial(mode, n=40):
+            for b in range(2):
+                tg.work[b] = None
+            tg.mode = mode
+            t = time_steps(torch, dev, step, n, 4, fence)
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / n
+        t_in = trial("inline")
+        t_as = trial("async")
+        chosen = "async" if t_as < 0.98 * t_in else "inline"
+        autotune = {"inline_ms_per_step": round(1e3 * t_in, 4), "async_ms_per_step": round(1e3 * t_as, 4), "chosen": chosen}
+        for b in range(2):
+            tg.work[b] = None
+        tg.mode = chosen
+        gather_kind = "native" if chosen == "inline" else "async"
+        nstep[0] = 0
     elapsed = time_steps(torch, dev, step, args.steps, args.warmup, fence)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -486,6 +509,8 @@ def main():
     }
     if gather_fallback:
         out["config"]["collective_fallback_from_native"] = gather_fallback
+    if autotune:
+        out["config"]["collective_autotune"] = autotune
     if rank == 0:
         path_gbs = value * 1e6 * bps / 1e9
         roof = {"bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
