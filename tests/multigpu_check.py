@@ -9,8 +9,9 @@ layout under gloo: tests/test_dist_cpu.py).  One process per GPU; runs BOTH coll
      block-contiguously (gsmcal.dist.shard_range: gsm_sync_demod.m:112 / multi_rtl_sdr_gsm_FCCH_scanner.m:60-65);
   2. every rank calibrates ITS shard on its GPU (gsmcal_calibrate_batch through the C ABI);
   3. the table is gathered (a) by torch.distributed over RCCL (gsmcal.dist.allgather_table and the bench's double-buffered
-     TableGatherer) and (b) by the native gsmcal_allgather_table, bootstrapped through an id file carrying this launch's
-     nonce, with a stale id file of another launch planted at the path first (ADVICE r2);
+     TableGatherer), (b) by the native gsmcal_allgather_table, bootstrapped through an id file carrying this launch's
+     nonce, with a stale id file of another launch planted at the path first, and (c) by bench.py's current N > 1
+     exchange: NativeTableGatherer (in line and on the side stream) on a communicator bootstrapped through the process group;
   4. every rank compares all gathered tables, row by row and bit for bit, with the table it computes for ALL units on its
      own GPU (unit independence makes that the expected result), and rank 0 checks unit 0 against the CPU oracle.
 
@@ -114,6 +115,30 @@ def main():
         r = recv.cpu().numpy()
         nat = np.concatenate([r[k * mx: k * mx + sizes[k]] for k in range(world)])
         assert np.array_equal(nat, full, equal_nan=True), f"native gsmcal_allgather_table, {num_units} units"
+        # (c) bench.py's N > 1 exchange as it runs now: the native communicator bootstrapped through the process group,
+        # NativeTableGatherer in line on the chain's stream and on the library's side stream, switching between the two the way the
+        # bench's warm-up autotune does
+        comm2 = gd.native_comm_from_process_group(ctx, dev)
+        try:
+            ntg = gd.NativeTableGatherer(ctx, comm2, sizes, gsmcal.TABLE_COLS, dev, mode="inline")
+            for mode in ("inline", "async", "inline"):
+                torch.cuda.synchronize(dev)
+                ntg.work = [None, None]
+                ntg.mode = mode
+                for step in range(4):
+                    b = step & 1
+                    ntg.wait(b)
+                    ntg.post(b, local_t + float(step))
+                for b in (0, 1):
+                    rows = ntg.rows(b)
+                    torch.cuda.synchronize(dev)
+                    if mode == "async":
+                        ctx.check(ctx.lib.gsmcal_allgather_sync(ctx.h, b), "gsmcal_allgather_sync")
+                    assert np.array_equal(rows.cpu().numpy(), full + float(2 + b), equal_nan=True), f"NativeTableGatherer {mode} buffer {b}, {num_units} units"
+                    assert np.array_equal(ntg.own_rows(b).cpu().numpy(), full[lo:hi] + float(2 + b), equal_nan=True)
+        finally:
+            torch.cuda.synchronize(dev)
+            comm2.close()
         if rank == 0 and num_units == 7:
             from oracle import gsmcal_oracle as oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
