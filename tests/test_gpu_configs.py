@@ -254,3 +254,15 @@ def test_scanner_pipeline_choices_change_no_bit(g_mod, ctx, monkeypatch, n_sampl
             cx.close()
         for p_ in (d_base, d_raw, d_out, d_pos, d_psn, d_cnt):
             ctx.free(p_)
+
+
+def test_multigpu_preflight_script_on_one_rank():
+    """tests/multigpu_check.py (the pre-flight for a node with several GPUs) with one rank: every collective path it covers --
+    torch's, the native one through an id file, bench.py's NativeTableGatherer in both placements -- on real calibration
+    tables; keeps the script from rotting while only one GPU is at hand."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multigpu_check.py"), "--gpus", "1", "--frames", "61"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "multigpu_check OK: rank 0/1" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
