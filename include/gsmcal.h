@@ -259,7 +259,11 @@ int gsmcal_comm_init_file(gsmcal_ctx* ctx, const char* path, int world, int rank
  * refuse files older than GSMCAL_COMM_STALE_S seconds (default 120) -- unsafe for a relaunch inside that window, which
  * would accept the dead launch's id.  Give every launch its own nonce (job id, launcher pid, start time).
  * gsmcal_comm_init_file derives one itself: GSMCAL_COMM_NONCE if set, else a hash of the launcher's run / job id
- * (TORCHELASTIC_RUN_ID, SLURM_JOB_ID, PBS_JOBID, LSB_JOBID) and MASTER_ADDR:MASTER_PORT; 0 only if none of these exist. */
+ * (TORCHELASTIC_RUN_ID unless it is torchrun's literal default "none", TORCHELASTIC_RESTART_COUNT, SLURM_JOB_ID,
+ * SLURM_STEP_ID, PBS_JOBID, LSB_JOBID) and MASTER_ADDR:MASTER_PORT; 0 only if none of these exist.  A nonce DERIVED this way
+ * may repeat from launch to launch (plain `torchrun`: RUN_ID "none", 127.0.0.1:29500 every time), so gsmcal_comm_init_file
+ * keeps the age test on for it: a record is accepted only with the right nonce AND younger than the stale window.  Only a
+ * nonce the caller chose (GSMCAL_COMM_NONCE, gsmcal_comm_init_file_nonce with nonce != 0) switches the age test off. */
 int gsmcal_comm_init_file_nonce(gsmcal_ctx* ctx, const char* path, unsigned long long nonce, int world, int rank,
                                 gsmcal_comm** out);
 /* The nonce gsmcal_comm_init_file derives from the environment (see above); 0 = the environment identifies no launch. */
@@ -269,6 +273,9 @@ unsigned long long gsmcal_comm_default_nonce(void);
  * gsmcal_comm_id_file_remove: rank 0's clean-up after the communicator is up. */
 int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int world, int rank,
                                  void* id_inout /* GSMCAL_COMM_ID_BYTES */, double timeout_s);
+/* ... with the age test on whatever the nonce (what gsmcal_comm_init_file runs for a nonce derived from the environment). */
+int gsmcal_comm_id_file_exchange_aged(const char* path, unsigned long long nonce, int world, int rank,
+                                      void* id_inout /* GSMCAL_COMM_ID_BYTES */, double timeout_s);
 int gsmcal_comm_id_file_remove(const char* path);
 void gsmcal_comm_destroy(gsmcal_comm* comm);
 /* d_all[r][i][c] = rank r's d_local[i][c]: rows_per_rank x cols doubles per rank (ranks with fewer units pad their block,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gsmcal_comm_init_file_nonce": (C.c_int, [C.c_void_p, C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmcal_comm_default_nonce": (C.c_ulonglong, []),
     "gsmcal_comm_id_file_exchange": (C.c_int, [C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_double]),
+    "gsmcal_comm_id_file_exchange_aged": (C.c_int, [C.c_char_p, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_double]),
     "gsmcal_comm_id_file_remove": (C.c_int, [C.c_char_p]),
     "gsmcal_comm_destroy": (None, [C.c_void_p]),
     "gsmcal_allgather_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -1886,7 +1886,10 @@ int gsmcal_comm_id_file_remove(const char* path) {
     return 0;
 }
 
-int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int world, int rank, void* id_inout, double timeout_s) {
+// age_test: also reject a record older than the stale window (GSMCAL_COMM_STALE_S, 120 s).  Always on for nonce 0; on as well
+// for a nonce that was only DERIVED from the environment (default_launch_nonce): plain torchrun gives every launch the same
+// MASTER_ADDR:MASTER_PORT, so a derived nonce may repeat across launches and must not switch the age test off.
+static int id_file_exchange(const char* path, unsigned long long nonce, bool age_test, int world, int rank, void* id_inout, double timeout_s) {
     if (!path || !id_inout || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
     const size_t rec = 16 + GSMCAL_COMM_ID_BYTES;
     unsigned char buf[16 + GSMCAL_COMM_ID_BYTES];
@@ -1917,8 +1920,8 @@ int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int
             memcpy(&magic, buf, 8);
             memcpy(&fn, buf + 8, 8);
             bool ok = got == rec && !more && magic == GSMCAL_ID_MAGIC && fn == nonce;
-            // no nonce to tell runs apart: a record older than the stale window belongs to a bootstrap that died
-            if (ok && nonce == 0) ok = have_sb && difftime(time(nullptr), sb.st_mtime) <= stale_s;
+            // no caller-chosen nonce to tell runs apart: a record older than the stale window belongs to a bootstrap that died
+            if (ok && (nonce == 0 || age_test)) ok = have_sb && difftime(time(nullptr), sb.st_mtime) <= stale_s;
             if (ok) { memcpy(id_inout, buf + 16, GSMCAL_COMM_ID_BYTES); return 0; }
         }
         usleep(10000);
@@ -1926,11 +1929,19 @@ int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int
     return GSMCAL_E_ARG;
 }
 
-int gsmcal_comm_init_file_nonce(gsmcal_ctx* c, const char* path, unsigned long long nonce, int world, int rank, gsmcal_comm** out) {
+int gsmcal_comm_id_file_exchange(const char* path, unsigned long long nonce, int world, int rank, void* id_inout, double timeout_s) {
+    return id_file_exchange(path, nonce, nonce == 0, world, rank, id_inout, timeout_s);
+}
+
+int gsmcal_comm_id_file_exchange_aged(const char* path, unsigned long long nonce, int world, int rank, void* id_inout, double timeout_s) {
+    return id_file_exchange(path, nonce, true, world, rank, id_inout, timeout_s);
+}
+
+static int comm_init_file(gsmcal_ctx* c, const char* path, unsigned long long nonce, bool age_test, int world, int rank, gsmcal_comm** out) {
     if (!c || !path || !out || world < 1 || rank < 0 || rank >= world) return GSMCAL_E_ARG;
     unsigned char id[GSMCAL_COMM_ID_BYTES];
     if (rank == 0) RET_IF(gsmcal_comm_get_unique_id(id));
-    if (gsmcal_comm_id_file_exchange(path, nonce, world, rank, id, 60.0) != 0) {
+    if (id_file_exchange(path, nonce, age_test, world, rank, id, 60.0) != 0) {
         c->err = rank == 0 ? "cannot publish the id file" : "timed out waiting for rank 0's id file (this run's nonce)";
         return GSMCAL_E_ARG;
     }
@@ -1939,16 +1950,28 @@ int gsmcal_comm_init_file_nonce(gsmcal_ctx* c, const char* path, unsigned long l
     return rc;
 }
 
+int gsmcal_comm_init_file_nonce(gsmcal_ctx* c, const char* path, unsigned long long nonce, int world, int rank, gsmcal_comm** out) {
+    return comm_init_file(c, path, nonce, nonce == 0, world, rank, out);
+}
+
 // The nonce gsmcal_comm_init_file uses when the caller names none: GSMCAL_COMM_NONCE if set, else a hash of what identifies
-// this LAUNCH to every one of its ranks -- the launcher's run id (torchrun / torch.distributed.run export TORCHELASTIC_RUN_ID),
-// a batch scheduler's job id, or the rendezvous address (MASTER_ADDR:MASTER_PORT) -- so that a record an earlier, crashed
-// bootstrap left at the path is never accepted.  0 only when the environment offers none of these: readers then
-// fall back to the age test (GSMCAL_COMM_STALE_S), which cannot tell a relaunch inside the stale window from this launch.
-static unsigned long long default_launch_nonce() {
-    if (const char* e = getenv("GSMCAL_COMM_NONCE")) return strtoull(e, nullptr, 0);
+// this LAUNCH to every one of its ranks -- the launcher's run id (TORCHELASTIC_RUN_ID, unless it is torchrun's literal default
+// "none") with its restart count, a batch scheduler's job id, and the rendezvous address (MASTER_ADDR:MASTER_PORT).  0 when the
+// environment offers none of these.  *strong = the caller chose it (GSMCAL_COMM_NONCE): only then may readers skip the age
+// test.  A derived nonce can repeat -- plain `torchrun` has RUN_ID "none" and the static 127.0.0.1:29500 in every launch -- so
+// records carrying it are still held to the stale window (GSMCAL_COMM_STALE_S): an id file a crashed bootstrap left behind is
+// rejected by the nonce when the launcher tells launches apart and by its age when it does not.
+static unsigned long long default_launch_nonce(bool* strong = nullptr) {
+    if (strong) *strong = false;
+    if (const char* e = getenv("GSMCAL_COMM_NONCE")) { if (strong) *strong = true; return strtoull(e, nullptr, 0); }
     std::string id;
-    for (const char* name : {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID"})
-        if (const char* v = getenv(name)) { if (*v) { id += name; id += '='; id += v; id += ';'; } }
+    for (const char* name : {"TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "SLURM_JOB_ID", "SLURM_STEP_ID", "PBS_JOBID", "LSB_JOBID"})
+        if (const char* v = getenv(name)) {
+            if (!*v) continue;
+            if (!strcmp(name, "TORCHELASTIC_RUN_ID") && !strcmp(v, "none")) continue;       // torch.distributed.run's default: identifies nothing
+            if (!strcmp(name, "TORCHELASTIC_RESTART_COUNT") && !strcmp(v, "0") && id.empty()) continue;   // (a first attempt without a run id says nothing either)
+            id += name; id += '='; id += v; id += ';';
+        }
     const char* ma = getenv("MASTER_ADDR");
     const char* mp = getenv("MASTER_PORT");
     if (ma && mp && *ma && *mp) { id += ma; id += ':'; id += mp; }
@@ -1961,7 +1984,9 @@ static unsigned long long default_launch_nonce() {
 unsigned long long gsmcal_comm_default_nonce(void) { return default_launch_nonce(); }
 
 int gsmcal_comm_init_file(gsmcal_ctx* c, const char* path, int world, int rank, gsmcal_comm** out) {
-    return gsmcal_comm_init_file_nonce(c, path, default_launch_nonce(), world, rank, out);
+    bool strong = false;
+    const unsigned long long nonce = default_launch_nonce(&strong);
+    return comm_init_file(c, path, nonce, !strong, world, rank, out);
 }
 
 void gsmcal_comm_destroy(gsmcal_comm* g) {

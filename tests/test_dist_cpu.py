@@ -196,7 +196,8 @@ def test_default_launch_nonce_comes_from_the_launcher_environment(monkeypatch):
     address; two launches differ, the ranks of one launch agree, and only a bare environment gives 0."""
     import gsmcal
     lib = gsmcal.load()
-    for k in ("GSMCAL_COMM_NONCE", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("GSMCAL_COMM_NONCE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "SLURM_JOB_ID", "SLURM_STEP_ID", "PBS_JOBID",
+              "LSB_JOBID", "MASTER_ADDR", "MASTER_PORT"):
         monkeypatch.delenv(k, raising=False)
     assert lib.gsmcal_comm_default_nonce() == 0
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
@@ -211,6 +212,60 @@ def test_default_launch_nonce_comes_from_the_launcher_environment(monkeypatch):
     assert c not in (0, a, b)
     monkeypatch.setenv("GSMCAL_COMM_NONCE", "0x1234")
     assert lib.gsmcal_comm_default_nonce() == 0x1234
+
+
+def test_plain_torchrun_environment_keeps_the_age_test(tmp_path, monkeypatch):
+    """under plain `torchrun` TORCHELASTIC_RUN_ID is the literal "none" and MASTER_ADDR:MASTER_PORT the static
+    127.0.0.1:29500, so every launch derives the SAME nonce.  "none" must count as absent (and the restart count must tell
+    two attempts of one run apart), and a record carrying a derived nonce must still be refused when it is older than the
+    stale window: an hour-old file planted with exactly this launch's derived nonce is not accepted."""
+    import struct
+    import threading
+    import time
+
+    import gsmcal
+    lib = gsmcal.load()
+    for k in ("GSMCAL_COMM_NONCE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "SLURM_JOB_ID", "SLURM_STEP_ID", "PBS_JOBID",
+              "LSB_JOBID", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    bare = lib.gsmcal_comm_default_nonce()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    assert lib.gsmcal_comm_default_nonce() == bare, "RUN_ID=none must identify nothing"
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert lib.gsmcal_comm_default_nonce() not in (0, bare), "a restarted attempt must not share the first attempt's nonce"
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-42")
+    assert lib.gsmcal_comm_default_nonce() not in (0, bare)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    nonce = lib.gsmcal_comm_default_nonce()
+    assert nonce == bare != 0
+    # an id file a crashed bootstrap of an EARLIER plain-torchrun launch left behind: same derived nonce, an hour old
+    path = tmp_path / "rccl_id"
+    stale_id, fresh_id = bytes([0xEE]) * 128, bytes(range(128))
+    path.write_bytes(struct.pack("<QQ", 0x3144494C41434D47, nonce) + stale_id)
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))
+    import ctypes as C
+
+    def aged(rank, ident, timeout):
+        buf = C.create_string_buffer(ident, 128)
+        return lib.gsmcal_comm_id_file_exchange_aged(str(path).encode(), nonce, 2, rank, buf, timeout), buf.raw
+
+    got = {}
+    t = threading.Thread(target=lambda: got.__setitem__("r", aged(1, bytes(128), 20.0)))
+    t.start()
+    time.sleep(0.5)
+    assert t.is_alive(), "a reader with a derived nonce accepted an hour-old record of the same nonce"
+    assert aged(0, fresh_id, 20.0)[0] == 0
+    t.join(timeout=30)
+    assert got["r"] == (0, fresh_id)
+    # the caller-chosen-nonce entry point keeps its contract: the nonce alone decides (an old record of THIS nonce is taken)
+    path.write_bytes(struct.pack("<QQ", 0x3144494C41434D47, 0x77) + stale_id)
+    os.utime(path, (old, old))
+    assert _exchange(lib, path, 0x77, 2, 1, bytes(128), 2.0) == (0, stale_id)
 
 
 def test_plain_bench_gpus_n_starts_its_own_ranks_and_fails_clearly_without_the_devices():
