@@ -370,26 +370,27 @@ def main():
     # =torch: torch.distributed's collective, round 3's path) -- tools/dist_cost.py has what each costs per step on one rank
     tg, gather_kind, ncomm, gather_fallback = None, "none", None, None
     if use_dist:
-        gather_kind = os.environ.get("GSMCAL_BENCH_GATHER", "native")
-        if gather_kind == "torch":
-            tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
-        else:
-            # (the native communicator has only ever run on one rank in this project's own sessions: if it cannot be set up on
-            # ANY rank, every rank falls back to torch.distributed's collective together and the line says so)
-            native_err = None
-            try:
-                if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back below)
-                    raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
-                ncomm = gdist.native_comm_from_process_group(ctx, dev)
-                tg = gdist.NativeTableGatherer(ctx, ncomm, sizes, gsmcal.TABLE_COLS, dev, mode="async" if gather_kind == "async" else "inline")
-            except Exception as e:  # noqa: BLE001
-                native_err = f"{type(e).__name__}: {e}"
-            bad = torch.tensor([0 if native_err is None else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            if int(bad.item()):
-                gather_fallback = native_err or "native communicator failed on another rank"
-                gather_kind, ncomm = "torch", None
-                tg = gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev)
+        # Which collective: decided in gsmcal.dist.choose_gatherer, identically on every rank.  The native communicator is set up
+        # and one CHECKED trial exchange runs on it (both buffer pairs, every peer's block compared), each under a time-out; if
+        # any rank fails or hangs there, ALL ranks fall back to torch.distributed's collective together and the line says so
+        # (the native path had only ever run on one rank).  GSMCAL_BENCH_GATHER=torch | native | async skips the choice.
+        want = os.environ.get("GSMCAL_BENCH_GATHER", "native")
+        holder = {}
+
+        def make_native():
+            if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back)
+                raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                holder["comm"] = gdist.native_comm_from_process_group(ctx, dev)
+                return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode="async" if want == "async" else "inline", stream=stream)
+
+        def verify(g):
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                gdist.verify_gatherer(g, gsmcal.TABLE_COLS, dev, lambda: stream.synchronize())
+
+        tg, gather_kind, gather_fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev), dev,
+                                                                 want=want, verify=verify, timeout_s=float(os.environ.get("GSMCAL_BENCH_NATIVE_TIMEOUT_S", "90")))
+        ncomm = holder.get("comm") if gather_kind != "torch" else None
     host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
 
@@ -426,22 +427,8 @@ def main():
     # timed over 40 steps, max over ranks, every rank takes the same decision.
     autotune = None
     if use_dist and gather_kind == "native" and "GSMCAL_BENCH_GATHER" not in os.environ:
-        def trial(mode, n=40):
-            for b in range(2):
-                tg.work[b] = None
-            tg.mode = mode
-            t = time_steps(torch, dev, step, n, 4, fence)
-            tt = torch.tensor([t], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item()) / n
-        t_in = trial("inline")
-        t_as = trial("async")
-        chosen = "async" if t_as < 0.98 * t_in else "inline"
-        autotune = {"inline_ms_per_step": round(1e3 * t_in, 4), "async_ms_per_step": round(1e3 * t_as, 4), "chosen": chosen}
-        for b in range(2):
-            tg.work[b] = None
-        tg.mode = chosen
-        gather_kind = "native" if chosen == "inline" else "async"
+        autotune = gdist.autotune_placement(tg, lambda mode: time_steps(torch, dev, step, 40, 4, fence) / 40, dev)
+        gather_kind = "native" if autotune["chosen"] == "inline" else "async"
         nstep[0] = 0
     elapsed = time_steps(torch, dev, step, args.steps, args.warmup, fence)
     if use_dist:
@@ -583,6 +570,13 @@ def main():
             out["parity_checked_streams"] = n_rank_checked
         print(json.dumps(out))
     if use_dist:
+        if gather_fallback and "TimeoutError" in gather_fallback:
+            # a helper thread of choose_gatherer is still stuck inside the abandoned native bootstrap / trial exchange: tearing the
+            # communicators down under it aborts the process after all work is done and reported -- leave without the tear-down
+            dist.barrier()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         if ncomm is not None:
             torch.cuda.synchronize(dev)
             ncomm.close()

@@ -46,6 +46,7 @@ class Context:
                               f"(this package has no CPU fallback)")
         self.h = h
         self.device = device
+        self.stream_handle = None if stream is None else int(stream)   # the caller's HIP stream (None: the context's own)
 
     def close(self):
         if getattr(self, "h", None):

@@ -90,6 +90,10 @@ class TableGatherer:
         off = self.rank * self.mx
         return self.recv[b][off: off + self.sizes[self.rank]]
 
+    def reset(self, mode=None):
+        for b in range(2):
+            self.wait(b)
+
 
 class NativeComm:
     """The same collective without PyTorch: gsmcal_allgather_table of the C ABI (RCCL, enqueued on the context's
@@ -137,7 +141,11 @@ class NativeTableGatherer:
     gsmcal_allgather_table_async -- the collective on the library's side stream behind an event, the gather of step i under
     the kernels of step i+1, at the price of that event (+14 us per step, tools/dist_cost.py)."""
 
-    def __init__(self, ctx, comm, sizes, cols, device, mode="inline", dtype=None):
+    def __init__(self, ctx, comm, sizes, cols, device, mode="inline", dtype=None, stream=None):
+        """`stream`: the torch stream that wraps the context's HIP stream (default: torch's current stream at construction).
+        The collective is enqueued by the library on the CONTEXT's stream, the pad copies and the re-assembly of uneven shards
+        by torch: both must be the same stream or the copy races the all-gather -- checked here when the context
+        knows its stream, and every torch operation of this class runs inside `torch.cuda.stream(stream)`."""
         import torch
         self.ctx, self.comm, self.mode = ctx, comm, mode
         self.sizes = list(sizes)
@@ -145,18 +153,34 @@ class NativeTableGatherer:
         self.mx = max(self.sizes)
         self.cols = int(cols)
         dtype = dtype or torch.float64
-        self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
+        if dtype != torch.float64:
+            raise TypeError("gsmcal_allgather_table moves doubles (ncclDouble): the table must be float64")
+        self.stream = stream if stream is not None else (torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None)
+        ctx_stream = getattr(ctx, "stream_handle", None)
+        if self.stream is not None and ctx_stream is not None and int(self.stream.cuda_stream) != int(ctx_stream):
+            raise ValueError("NativeTableGatherer: the torch stream is not the context's stream -- pad copies would race the collective")
+        with self._on_stream():
+            self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
+            self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
         self.work = [None, None]
+
+    def _on_stream(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def post(self, b, local):
         import ctypes as C
+        import torch
         if local.shape[0] != self.sizes[self.rank]:
             raise ValueError("local table does not match this rank's shard")
+        if local.dtype != torch.float64:
+            raise TypeError("gsmcal_allgather_table moves doubles (ncclDouble): the table must be float64")
         self.wait(b)
         src = local
         if local.shape[0] != self.mx or not local.is_contiguous():     # uneven shards: pad to the largest (NaN rows are dropped by rows())
-            self.send[b][: local.shape[0]].copy_(local)
+            with self._on_stream():
+                self.send[b][: local.shape[0]].copy_(local)
             src = self.send[b]
         if self.mode == "async":
             self.ctx.check(self.ctx.lib.gsmcal_allgather_table_async(self.ctx.h, self.comm.h, C.c_void_p(src.data_ptr()), self.mx, self.cols,
@@ -177,11 +201,112 @@ class NativeTableGatherer:
             self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
         if all(s == self.mx for s in self.sizes):
             return self.recv[b]
-        return torch.cat([self.recv[b][r * self.mx: r * self.mx + self.sizes[r]] for r in range(self.world)], dim=0)
+        with self._on_stream():
+            return torch.cat([self.recv[b][r * self.mx: r * self.mx + self.sizes[r]] for r in range(self.world)], dim=0)
 
     def own_rows(self, b):
         off = self.rank * self.mx
         return self.recv[b][off: off + self.sizes[self.rank]]
+
+    def reset(self, mode=None):
+        """forget the posted buffers (between two timing trials) and optionally switch the placement of the collective"""
+        for b in range(2):
+            self.work[b] = None
+        if mode is not None:
+            self.mode = mode
+
+
+# ---- N > 1 decisions that every rank must take identically (VERDICT r4 #7, ADVICE r4): which collective, and where it sits ----
+def all_max(value, device="cpu", group=None):
+    """MAX over the ranks of one float (the agreement primitive of the two functions below)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def call_with_timeout(fn, timeout_s):
+    """fn() on a helper thread; TimeoutError when it has not returned after timeout_s seconds (the thread is left behind as a
+    daemon: a bootstrap stuck inside ncclCommInitRank cannot be cancelled, only abandoned).  timeout_s None / <= 0: plain call."""
+    if not timeout_s or timeout_s <= 0:
+        return fn()
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box["e"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        raise TimeoutError(f"no answer within {timeout_s:g} s")
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
+def choose_gatherer(make_native, make_torch, device="cpu", group=None, want="native", verify=None, timeout_s=90.0):
+    """The table gatherer every rank of the job uses -- the SAME kind on every rank.
+
+    want "torch": torch.distributed's collective (TableGatherer).  Otherwise `make_native()` builds the C ABI's own
+    communicator + NativeTableGatherer and `verify(tg)` (optional) runs one checked trial exchange; either may raise or
+    hang (timeout_s each).  The ranks then agree by one all-reduce: if ANY rank failed, ALL ranks fall back to
+    `make_torch()` -- a rank never keeps a native communicator its peers gave up on.
+    Returns (gatherer, kind, fallback_reason or None); kind is "torch" or `want`."""
+    if want == "torch":
+        return make_torch(), "torch", None
+    tg, err = None, None
+    try:
+        tg = call_with_timeout(make_native, timeout_s)
+        if verify is not None:
+            call_with_timeout(lambda: verify(tg), timeout_s)
+    except BaseException as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if all_max(0.0 if err is None else 1.0, device, group) > 0.0:
+        return make_torch(), "torch", err or "native collective failed on another rank"
+    return tg, want, None
+
+
+def autotune_placement(tg, measure, device="cpu", group=None, margin=0.98, modes=("inline", "async")):
+    """Where the native all-gather sits, decided by measurement, identically on every rank: in line on the chain's stream
+    (costs the collective's latency per step) or on the side stream behind an event (hides it under the next step, costs
+    the event).  `measure(mode)` -> seconds per step on THIS rank with tg.mode == mode (called in the same order on every
+    rank: it contains collectives).  The MAX over ranks of each figure decides -- a rank that happens to prefer the other
+    placement still follows -- and the second mode must win by `margin` to displace the first.
+    Returns {"<mode>_ms_per_step": ..., "chosen": mode}."""
+    worst = {}
+    for m in modes:
+        tg.reset(m)
+        worst[m] = all_max(measure(m), device, group)
+    chosen = modes[1] if worst[modes[1]] < margin * worst[modes[0]] else modes[0]
+    tg.reset(chosen)
+    out = {f"{m}_ms_per_step": round(1e3 * worst[m], 4) for m in modes}
+    out["chosen"] = chosen
+    return out
+
+
+def verify_gatherer(tg, cols, device, sync, timeout_s=60.0):
+    """One checked exchange on both buffer pairs of a gatherer before the job commits to it: rank r sends rows filled with
+    1000 r + row + col/16, every rank checks every peer's block.  `sync()` must complete the work enqueued so far (and may
+    itself be guarded by the caller's timeout).  Raises on a wrong table."""
+    import torch
+    want = torch.cat([1000.0 * r + torch.arange(n, dtype=torch.float64).reshape(n, 1) + torch.arange(cols, dtype=torch.float64).reshape(1, cols) / 16.0
+                      for r, n in enumerate(tg.sizes)], dim=0)
+    n = tg.sizes[tg.rank]
+    local = (1000.0 * tg.rank + torch.arange(n, dtype=torch.float64).reshape(n, 1) + torch.arange(cols, dtype=torch.float64).reshape(1, cols) / 16.0).to(device)
+    for b in range(2):
+        tg.post(b, local)
+    got = [tg.rows(b).clone() for b in range(2)]
+    call_with_timeout(sync, timeout_s)
+    for b in range(2):
+        if not torch.equal(got[b].cpu(), want):
+            raise RuntimeError(f"trial all-gather returned a wrong table on rank {tg.rank} (buffer pair {b})")
+        tg.work[b] = None
 
 
 def native_comm_from_process_group(ctx, device, group=None):

@@ -98,6 +98,138 @@ def test_bench_exchange_step_under_gloo(num_units):
             assert np.array_equal(res[r][step], want), f"rank {r} step {step}"
 
 
+class _FakeNative:
+    """stands in for NativeTableGatherer in the decision-logic tests: same post / rows / reset surface, moves the rows with
+    a process group of its OWN (as the native communicator is a communicator of its own: a rank stuck in it does not
+    disturb the job's group, on which the ranks agree what to do)"""
+
+    def __init__(self, sizes, cols, rank, group, mode="inline"):
+        self.sizes, self.rank, self.mode, self.cols, self.group = list(sizes), rank, mode, cols, group
+        self.mx = max(self.sizes)
+        self.work = [None, None]
+        self.out = [None, None]
+        self.resets = []
+
+    def post(self, b, local):
+        send = torch.full((self.mx, self.cols), float("nan"), dtype=torch.float64)
+        send[: local.shape[0]] = local
+        recv = torch.zeros((len(self.sizes) * self.mx, self.cols), dtype=torch.float64)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self.out[b] = torch.cat([recv[r * self.mx: r * self.mx + n] for r, n in enumerate(self.sizes)], dim=0)
+        self.work[b] = True
+
+    def rows(self, b):
+        return self.out[b]
+
+    def reset(self, mode=None):
+        self.work = [None, None]
+        if mode is not None:
+            self.mode = mode
+        self.resets.append(mode)
+
+
+def _decision_worker(rank, world, scenario, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import gsmcal
+    from gsmcal import dist as gd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = gd.shard_sizes(7, world)
+    cols = gsmcal.TABLE_COLS
+    side = dist.new_group(backend="gloo", timeout=__import__("datetime").timedelta(seconds=20))
+
+    def make_native():
+        if scenario == "rank1_setup_raises" and rank == 1:
+            raise RuntimeError("ncclCommInitRank: unhandled system error (planted)")
+        if scenario == "rank1_setup_hangs" and rank == 1:
+            time.sleep(30.0)
+        return _FakeNative(sizes, cols, rank, side)
+
+    def verify(tg):
+        if scenario == "rank0_trial_wrong" and rank == 0:
+            raise RuntimeError("trial all-gather returned a wrong table (planted)")
+        gd.verify_gatherer(tg, cols, "cpu", lambda: None)
+
+    tg, kind, why = gd.choose_gatherer(make_native, lambda: gd.TableGatherer(sizes, cols, torch.device("cpu")), "cpu",
+                                       want="torch" if scenario == "torch_asked" else "native", verify=verify, timeout_s=3.0)
+    out = {"kind": kind, "why": why, "type": type(tg).__name__}
+    if kind == "native":
+        # the two ranks measure OPPOSITE preferences: the max over ranks must decide, identically
+        if scenario == "opposite_preferences":
+            cost = {"inline": 0.100 if rank == 0 else 0.300, "async": 0.200 if rank == 0 else 0.150}
+        elif scenario == "async_wins":
+            cost = {"inline": 0.300, "async": 0.100 + 0.01 * rank}
+        else:
+            cost = {"inline": 0.100 + 0.001 * rank, "async": 0.099}        # within the margin: the first mode stays
+        seen = []
+
+        def measure(mode):
+            assert tg.mode == mode
+            seen.append(mode)
+            dist.barrier()                                   # (a measurement contains collectives: same order on every rank)
+            return cost[mode]
+
+        out["tune"] = gd.autotune_placement(tg, measure, "cpu")
+        out["mode"], out["seen"] = tg.mode, seen
+    # whatever was chosen must move a table correctly on both ranks
+    lo, hi = gd.shard_range(7, world, rank)
+    local = torch.tensor(np.stack([_unit_row(u, cols) for u in range(lo, hi)]))
+    tg.post(0, local)
+    out["table_ok"] = bool(np.array_equal(tg.rows(0).numpy(), np.stack([_unit_row(u, cols) for u in range(7)])))
+    q.put((rank, out))
+    dist.barrier()
+    if out["why"] and "TimeoutError" in out["why"]:
+        # a helper thread is still stuck inside the abandoned trial exchange: tearing the process group down under it aborts.
+        # Leave without the tear-down (what bench.py does after such a fall-back, once its line is printed).
+        q.close()
+        q.join_thread()
+        os._exit(0)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["all_fine", "rank1_setup_raises", "rank1_setup_hangs", "rank0_trial_wrong", "torch_asked",
+                                      "opposite_preferences", "async_wins"])
+def test_every_rank_takes_the_same_collective_decision(scenario):
+    """bench.py's N > 1 decisions (gsmcal.dist.choose_gatherer / autotune_placement) on two gloo ranks --
+    the native set-up fails or hangs on ONE rank, the trial exchange fails on one rank, the two ranks measure opposite
+    placements: both ranks must end on the same gatherer kind and the same placement, and the table must still arrive."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (hash(scenario) % 97)
+    procs = [ctx.Process(target=_decision_worker, args=(r, world, scenario, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["kind"] == b["kind"] and a["type"] == b["type"], (a, b)
+    assert a["table_ok"] and b["table_ok"]
+    if scenario in ("rank1_setup_raises", "rank1_setup_hangs", "rank0_trial_wrong"):
+        assert a["kind"] == "torch" and a["type"] == "TableGatherer"
+        failed, other = (b, a) if scenario != "rank0_trial_wrong" else (a, b)
+        assert "planted" in failed["why"] or "TimeoutError" in failed["why"], failed
+        # the healthy rank either learns of it at the agreement step or times out in a trial exchange its peer never joined
+        assert other["why"] == "native collective failed on another rank" or "TimeoutError" in other["why"], other
+    elif scenario == "torch_asked":
+        assert a["kind"] == "torch" and a["why"] is None and b["why"] is None
+    else:
+        assert a["kind"] == "native" and a["why"] is None
+        assert a["tune"] == b["tune"] and a["mode"] == b["mode"] == a["tune"]["chosen"]
+        assert a["seen"] == b["seen"] == ["inline", "async"]
+        if scenario == "opposite_preferences":           # max over ranks: inline 0.300, async 0.200
+            assert a["tune"] == {"inline_ms_per_step": 300.0, "async_ms_per_step": 200.0, "chosen": "async"}
+        elif scenario == "async_wins":
+            assert a["tune"]["chosen"] == "async"
+        else:
+            assert a["tune"]["chosen"] == "inline"
+
+
 def test_shard_ranges_cover_all_units():
     from gsmcal import dist as gd
     for u in (1, 7, 64, 102400):
