@@ -108,6 +108,12 @@ void gsmcal_ctx_destroy(gsmcal_ctx* ctx);
 int gsmcal_sync(gsmcal_ctx* ctx);
 const char* gsmcal_last_error(gsmcal_ctx* ctx);
 const char* gsmcal_version(void);
+/* Diagnostics of the batch path's fused tail (one launch for everything behind the fine search's chunk sweep: its workgroups
+ * exchange results inside the launch).  Several contexts may drive one GPU from several host threads; the library lets only one
+ * such launch of the process be in flight per device and gives the later caller the four-launch tail (same results).
+ * fused_launches: batch calls of this context that took the fused tail; gate_fallbacks: calls that would have but found
+ * another context's fused tail unfinished (or ran inside the caller's own stream capture, where replays cannot be gated). */
+int gsmcal_fused_tail_stats(gsmcal_ctx* ctx, unsigned long long* fused_launches, unsigned long long* gate_fallbacks);
 /* device memory helpers so a host program needs no HIP headers */
 int gsmcal_dev_alloc(gsmcal_ctx* ctx, size_t bytes, void** dptr);
 int gsmcal_dev_free(gsmcal_ctx* ctx, void* dptr);

@@ -68,6 +68,12 @@ class Context:
     def sync(self):
         self.check(self.lib.gsmcal_sync(self.h), "gsmcal_sync")
 
+    def fused_tail_stats(self):
+        """(batch calls that took the fused tail, calls the one-fused-tail-per-device gate sent to the four-launch tail)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self.check(self.lib.gsmcal_fused_tail_stats(self.h, C.byref(a), C.byref(b)), "gsmcal_fused_tail_stats")
+        return int(a.value), int(b.value)
+
     # ---- thresholds (gsmcal_params: the constants the reference hard-codes) ----
     def get_params(self):
         p = _lib.Params()

@@ -1057,28 +1057,11 @@ __global__ void __launch_bounds__(FV_THREADS) k_fine_verify(const StreamState* _
     DEV_STAMP(KID_VERIFY, blockIdx.y * gridDim.x + blockIdx.x, 2);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_post_chain: everything behind the fine search's chunk sweep in ONE launch -- the exact last word of the fine search
-// (fine_verify_body) and the three per-burst stages (k_burst_tone<1> -> k_window_sch -> k_burst_tone<0>) with the
-// reference's decision steps between them.  grid (H, S), block 512: workgroup (w, s) handles window w of stream s in every
-// stage.  The stages of one stream are separated by a PER-STREAM barrier instead of a kernel boundary: every workgroup of
-// the stream arrives on the stream's counter; the last one to arrive runs the decision step (on the state read past the
-// caches, written back write-through and drained) and raises the stream's generation word; the others poll it (one lane,
-// relaxed agent-scope loads, s_sleep).  No release / acquire fence anywhere: every word that crosses workgroups inside the
-// launch travels by write-through stores and L1-bypassing loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1
-// stores + sc1 loads both sides), so the eight L2s are neither written back nor invalidated.  What it saves over four
-// launches: streams no longer wait for the slowest workgroup of the whole grid at every stage, and the launch ramps.
-// Forward progress: a waiting workgroup waits only for workgroups of its own stream, which sit next to it in dispatch
-// order (blockIdx.y = stream), so with in-order dispatch the earliest unfinished stream always has (or is next to get) all
-// its workgroups resident, for any grid size.  A poll that runs out (never observed) marks the stream GSMCAL_E_HIP instead
-// of hanging the queue.
-// ------------------------------------------------------------------------------------------------
 #define PC_THREADS 512
 struct PostChainArgs {
     GatherArgs ga1, ga_sch, ga0;       // burst windows at level lvl+1, SCH search windows, post-SCH burst windows
     StepArgs sa;                       // one set of step arguments serves every decision step (NB = 1)
-    unsigned* ctr;                     // per stream: arrivals (monotonic inside the launch, re-armed by the last tail)
-    unsigned* gen;                     // per stream: stages whose decision step is complete
+    unsigned long long* done;          // pinned host word of the context: += 1 per finished stream (gsmcal_ctx::fused_done; nullptr: not counted)
     int lvl_fine, lvl_sch, lvl_post;   // input levels of the three reference functions
     int nfft, ov, len_ts, sch_nshift, fine_nshift, H;
     const cplx* tw_g; const cplx* ts;
@@ -1087,85 +1070,34 @@ struct PostChainArgs {
     int with_totals, pad;
 };
 
-// barrier of stream blockIdx.y after stage `stage` (0-based) + the stream's decision `steps`, run by the last arriver
-__device__ __forceinline__ void stream_stage_barrier(StreamState* __restrict__ sts, const PostChainArgs& a, int stage, int steps,
-                                                     int lvl_a, int lvl_b, unsigned char* smem) {
-    __shared__ int sh_last;
-    const int s = blockIdx.y;
-    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1 + 3 * stage);      // (development build: arrival, decision done, released)
-    // this workgroup's hand-over values were stored write-through; every wave waits until its own are acknowledged
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = atomicAdd(&a.ctr[s], 1u);           // relaxed, agent scope
-        sh_last = old == (unsigned)(gridDim.x * (stage + 1) - 1);
-    }
-    __syncthreads();
-    if (sh_last) {                                               // block-uniform
-        step_body<true, true>(sts, a.sa, steps, lvl_a, lvl_b, s, (StreamState*)smem);
-        __syncthreads();
-        DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 2 + 3 * stage);
-        if (threadIdx.x == 0) __hip_atomic_store(&a.gen[s], (unsigned)(stage + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (threadIdx.x == 0) {
-        long spins = 0;
-        while (__hip_atomic_load(&a.gen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(stage + 1)) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > 40000000L) {                           // ~ seconds: a peer never came (not observed); fail, do not hang
-                atomicMin(&sts[s].status, GSMCAL_E_HIP);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 3 + 3 * stage);
-}
-
-__global__ void __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_post_chain(StreamState* __restrict__ sts, PostChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
-    // stage 0: FCCH_fine_correction.m:48-52, exact last word per window -> FINE_DECIDE (:52-137)
-    fine_verify_body<PC_THREADS>(sts, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
-                                 a.cert, a.n_open, smem);
-    stream_stage_barrier(sts, a, 0, STEP_FINE_DECIDE, a.lvl_fine, 0, smem);
-    // stage 1: bursts of the resampled stream (:141-165, :185-196) -> CARRIER_DECIDE + SCH window setup
-    burst_tone_body<1>(sts, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem);
-    stream_stage_barrier(sts, a, 1, STEP_CARRIER_DECIDE | STEP_SCH_SETUP, a.lvl_fine, a.lvl_sch, smem);
-    // stage 2: SCH_corr_rate_correction.m:45-55 -> SCH_DECIDE (:59-181) + post-SCH window setup
-    window_sch_body(sts, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem);
-    stream_stage_barrier(sts, a, 2, STEP_SCH_DECIDE | STEP_POST_SETUP, a.lvl_sch, a.lvl_post, smem);
-    // stage 3: carrier_correct_post_SCH.m:51-79 -> POST_DECIDE (:75-83) + the table row (gsm_sync_demod.m:123-124)
-    burst_tone_body<0>(sts, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem);
-    {
-        __shared__ int sh_fin;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = atomicAdd(&a.ctr[blockIdx.y], 1u);
-            sh_fin = old == (unsigned)(gridDim.x * 4 - 1);
-            if (sh_fin) {                                        // every workgroup of the stream is past its last poll: re-arm
-                atomicExch(&a.ctr[blockIdx.y], 0u);
-                __hip_atomic_store(&a.gen[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        if (sh_fin) step_body<true>(sts, a.sa, a.with_totals ? (STEP_POST_DECIDE | STEP_TOTALS) : STEP_POST_DECIDE, a.lvl_post, 0,
-                                    blockIdx.y, (StreamState*)smem);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_post_chain_r: k_post_chain with REPLICATED decision steps.  Every workgroup of a stream keeps its own copy of the
-// stream's state in LDS for the whole launch.  A stage ends with each workgroup publishing its two result words (tone
-// frequency + gate SNR, SCH position + edge flag, peak power + shift/bin) as 8-byte write-through granules in the stream's
-// exchange block; it then reads the granules of all H workgroups of its stream (one lane per granule, polling past the
-// L1 until none is EMPTY) and runs the reference's decision step ITSELF on its own LDS copy -- the same instructions on
-// the same inputs in every workgroup, so all copies stay identical.  No counter, no last arriver, no state written and read
-// back through memory, no flag: after the slowest workgroup of the stream has published, its peers continue as soon as
-// they see its granule (~1 us) and have run the step on LDS (~1.5 us).  Workgroup 0 of the stream writes the table row and
-// the final state.  The exchange block is double-buffered by the parity of a per-stream launch counter (each workgroup
-// clears its own granules of the other parity on entry), so the launch can be replayed from a hipGraph unchanged.
-// EMPTY = all ones (a NaN no computation produces: published NaNs are canonicalised).
+// k_post_chain_r: everything behind the fine search's chunk sweep in ONE launch -- the exact last word of the fine search
+// (fine_verify_body) and the three per-burst stages (burst_tone_body<1> -> window_sch_body -> burst_tone_body<0>) with the
+// reference's decision steps between them, REPLICATED.  grid (H, S), block 512: workgroup (w, s) handles window w of stream
+// s in every stage and keeps its own copy of the stream's state in LDS for the whole launch.  A stage ends with each
+// workgroup publishing its two result words (tone frequency + gate SNR, SCH position + edge flag, peak power + shift/bin)
+// as 8-byte write-through granules in the stream's exchange block; it then reads the granules of all H workgroups of its
+// stream (one lane per granule, polling past the L1 until none is EMPTY) and runs the reference's decision step ITSELF on
+// its own LDS copy -- the same instructions on the same inputs in every workgroup, so all copies stay identical.  No
+// counter, no last arriver, no state written and read back through memory, no flag, no fence (every word that crosses
+// workgroups travels by sc1 write-through stores and L1-bypassing loads: MI355X_MICROARCH.md, inter-workgroup visibility):
+// after the slowest workgroup of the stream has published, its peers continue as soon as they see its granule (~1 us) and
+// have run the step on LDS (~1.5 us).  Workgroup 0 of the stream writes the table row and the final state.  The exchange
+// block is double-buffered by the parity of a per-stream launch counter (each workgroup clears its own granules of the
+// other parity on entry), so the launch can be replayed from a hipGraph unchanged.  EMPTY = all ones (a NaN no computation
+// produces: published NaNs are canonicalised).
+//
+// Forward progress.  A workgroup waits only for the H workgroups of its own stream, which are neighbours in dispatch order
+// (blockIdx.y = stream): the oldest unfinished stream of the launch is first in line for every slot that frees, so the
+// launch advances whenever the device gives it slots at all -- other tenants (another context's kernels, RCCL, a kernel
+// hogging the CUs) only delay it, like any kernel.  What could stop it is a SECOND spinning launch holding the slots this
+// one's next workgroups need while waiting for slots this one holds; the host therefore never has two fused tails of this
+// process in flight on one device (host_plan.h: fused_gate -- the later caller takes the four-launch tail).  The poll
+// limit below (~a minute) only keeps a logic error from hanging the queue for good; it is not part of normal operation.
+// (A take-over scheme -- a workgroup whose poll runs out computes the missing peer's window itself -- was built in round
+// 5 and dropped: every form of it (a loop around the stage bodies, a restart loop around the kernel, an out-of-line cold
+// helper) cost 0.9-1.5 KB of scratch per lane in a kernel that has 16 B, and a scratch frame that size delays the launch
+// of every wave: NOTES_r05.md.)
 // ------------------------------------------------------------------------------------------------
 #define PCR_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define PCR_STATE_BYTES ((sizeof(StreamState) + 15) & ~(size_t)15)
@@ -1318,6 +1250,10 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
         d_post_decide(sh, s, a.sa.ov, a.sa.carrier_freq, a.lvl_post, lane); wsync();
         if (a.with_totals) d_totals(sh, s, a.sa.table, a.sa.pos_info_out, a.sa.r_len_out, lane);
         StateLds::store(sts + s, sh, lane);
-        if (lane == 0) epoch[s] = par + 1u;                         // (only the parity matters)
+        if (lane == 0) {
+            epoch[s] = par + 1u;                                    // (only the parity matters)
+            // the host's gate (one fused tail of the process in flight per device) reads this pinned word: fire and forget
+            if (a.done) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }

@@ -99,3 +99,39 @@ def pool_map(fn, jobs, max_workers=32):
         return [fn(j) for j in jobs]
     with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
         return list(ex.map(fn, jobs, chunksize=1))
+
+
+def oracle_job_safe(job):
+    """oracle_job that reports the reference's index errors (MATLAB would raise: the ABI answers GSMCAL_E_INDEX) instead of
+    raising in the worker: -> (dict or None, message or None)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import gsmcal_oracle as oracle
+    raw, coef, ts, fc = job
+    try:
+        return oracle.calibrate_stream(raw, coef, ts, fc), None
+    except oracle.MatlabIndexError as e:
+        return None, str(e)
+
+
+def scan_units_job(job):
+    """job = (base captures, first unit, count, coef): oracle.scan_capture over the host twins of the device-expanded captures
+    [first, first + count) -> list of dicts (snr, num_hit, coarse_pos, coarse_snr)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from gsmcal import synth
+    from oracle import gsmcal_oracle as oracle
+    base, first, count, coef = job
+    out = []
+    for u in range(first, first + count):
+        r = oracle.scan_capture(synth.expand_capture(base, u), coef)
+        out.append({k: r[k] for k in ("snr", "num_hit", "coarse_pos", "coarse_snr")})
+    return out

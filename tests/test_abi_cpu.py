@@ -175,7 +175,7 @@ def test_params_defaults_are_the_reference_literals(gsmcal_mod):
 
 
 def test_named_library_is_never_rebuilt_and_must_exist(tmp_path):
-    """GSMCAL_LIB names another build of the library (tools/ab.sh, tools/devtiming.py): it is loaded as it is -- a missing
+    """GSMCAL_LIB names another build of the library (tools/ab_session.sh, tools/devtiming.py): it is loaded as it is -- a missing
     file is an error, not a reason to compile the current sources into that name (which made two 'different' builds equal)."""
     import subprocess
     import sys

@@ -256,6 +256,48 @@ def test_scanner_pipeline_choices_change_no_bit(g_mod, ctx, monkeypatch, n_sampl
             ctx.free(p_)
 
 
+def test_scanner_batch_of_2100_distinct_captures_every_capture_against_the_oracle(g_mod, ctx):
+    """a pipelined scanner batch (2 100 captures: 8 stages, front kernels launched in two parts, the detector
+    computing its SNRs in place) with EVERY capture -- not a sample -- through oracle.scan_capture: num_hit and hit positions
+    exact, snr and the hits' SNRs within 1e-8 dB.  The captures are distinct (gsmcal_synth_expand_dev; synth.expand_capture is
+    the host twin the oracle's workers rebuild them with).  multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,163-186."""
+    g = g_mod
+    D, K, n = 2100, 12, 260000
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)
+    base = np.stack([g.synth.make_stream(dongle=7300, arfcn=i, num_frames=26, bcch=i % 4 != 3,
+                                         **({"snr_db": 4.0 + i} if i % 4 == 1 else {}))[0][: 2 * n] for i in range(K)])
+    H = g.MAX_HITS
+    d_base, d_raw = ctx.alloc(base.nbytes), ctx.alloc(D * 2 * n)
+    d_out, d_pos, d_psn, d_cnt = ctx.alloc(D * 16), ctx.alloc(D * H * 8), ctx.alloc(D * H * 8), ctx.alloc(D * 4)
+    try:
+        ctx.h2d(d_base, base)
+        g.synth_expand_dev(d_base, K, n, d_raw, D, first_unit=0, ctx=ctx)
+        ctx.sync()
+        per = 25
+        want = [r for chunk in parity.pool_map(parity.scan_units_job, [(base, lo, min(per, D - lo), coef) for lo in range(0, D, per)],
+                                               max_workers=128) for r in chunk]
+        assert len(want) == D
+        for rep in range(3):                                          # eager, captured, replayed
+            g.fcch_scan_batch_dev(d_raw, D, n, coef, d_out, d_pos, d_psn, d_cnt, ctx=ctx)
+            ctx.sync()
+            sn = np.empty((D, 2)); ps = np.empty((D, H)); pn = np.empty((D, H)); cn = np.empty(D, dtype=np.int32)
+            ctx.d2h(sn, d_out); ctx.d2h(ps, d_pos); ctx.d2h(pn, d_psn); ctx.d2h(cn, d_cnt)
+            for u in range(D):
+                live = want[u]
+                assert live["num_hit"] == sn[u, 1], f"call {rep} unit {u}: num_hit {sn[u, 1]} vs oracle {live['num_hit']}"
+                assert abs(live["snr"] - sn[u, 0]) < parity.SNR_ATOL, f"call {rep} unit {u}: snr"
+                k = cn[u]
+                if live["coarse_pos"][0] == -1.0:
+                    assert k == 0 and ps[u, 0] == -1.0, f"call {rep} unit {u}: the oracle found no hit"
+                else:
+                    parity.assert_positions(ps[u, :k], live["coarse_pos"], f"call {rep} unit {u}: positions")
+                    assert np.allclose(pn[u, :k], live["coarse_snr"], rtol=0, atol=parity.SNR_ATOL), f"call {rep} unit {u}: hit SNRs"
+        assert np.sum(cn > 0) > D // 4
+    finally:
+        for p_ in (d_base, d_raw, d_out, d_pos, d_psn, d_cnt):
+            ctx.free(p_)
+
+
 def test_multigpu_preflight_script_on_one_rank():
     """tests/multigpu_check.py (the pre-flight for a node with several GPUs) with one rank: every collective path it covers --
     torch's, the native one through an id file, bench.py's NativeTableGatherer in both placements -- on real calibration

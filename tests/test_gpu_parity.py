@@ -447,7 +447,7 @@ def test_front_end_variants_agree(g, setup, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"GSMCAL_CERT": "0"}, {"GSMCAL_PRESCREEN": "0"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2"},
                                  {"GSMCAL_FUSE_GATHER": "0"}, {"GSMCAL_SNR_FULL": "0"}, {"GSMCAL_SNR_SCREEN_DB": "-300"},
-                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"}, {"GSMCAL_POST_REPL": "0"},
+                                 {"GSMCAL_SNR_SCREEN_DB": "30"}, {"GSMCAL_REUSE_L0": "0"}, {"GSMCAL_FUSE_POST": "0"},
                                  {"GSMCAL_FCERT_S47": "0"}, {"GSMCAL_POST_SLOTS": "2"}, {"GSMCAL_LANES": "4", "GSMCAL_LANE_MIN": "2", "GSMCAL_LANE_STAGGER": "1"},
                                  {"GSMCAL_SNR_FULL": "0", "GSMCAL_SNR_INLINE_MIN": "0"}])
 def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
@@ -455,7 +455,7 @@ def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     hop walk on its own spectra / on an unscreened SNR table / falling back because the screening level is above every
     threshold, per-burst gathers filtering their raw bytes again instead of reading the fine windows, the four launches behind
     the chunk sweep instead of the fused k_post_chain_r (per-stream exchange inside one launch, decision steps replicated in
-    every workgroup), and the fused chain with one deciding workgroup per stream (k_post_chain): identical tables."""
+    every workgroup): identical tables."""
     raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in range(40, 48)])
     ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
     for k, v in env.items():
@@ -556,6 +556,125 @@ def test_1024_stream_batch_on_staggered_lanes(g, setup):
         for i in range(1024):
             assert np.array_equal(out["table"][i], ref["table"][i % 8], equal_nan=True), i
         assert all(np.array_equal(out["pos_info"][i], ref["pos_info"][i % 8]) for i in range(0, 1024, 37))
+
+
+def _mixed_draw(i, rng):
+    """tests/sweep_parity.py's distribution: low SNR, larger ppm, carriers without a BCCH, nothing pre-selected"""
+    kw = {}
+    if i % 5 == 1:
+        kw["snr_db"] = float(rng.uniform(5, 15))
+    if i % 7 == 2:
+        kw["sampling_ppm"] = float(rng.uniform(-300, 300))
+    if i % 11 == 3:
+        kw["bcch"] = False
+    if i % 13 == 4:
+        kw["carrier_ppm"] = float(rng.uniform(-60, 60))
+    return kw
+
+
+@pytest.mark.parametrize("n_streams", [576, 1024])
+def test_wide_batch_of_distinct_streams_every_row_against_the_oracle(g, setup, n_streams):
+    """the THROUGHPUT code paths (more than 128 streams per lane: k_coarse_scan<INL>, the four-launch tail with
+    stream_tail decisions, staggered lanes, graph replay of the forked plan) on DISTINCT streams -- 576 (two lanes of 288) and
+    1 024 (four staggered lanes of 256) seeded 61-frame captures drawn like tests/sweep_parity.py (every 5th at 5-15 dB, large
+    ppm, carriers without a BCCH, nothing pre-selected), ONE calibrate call, EVERY row through parity.compare_stream; called
+    three times (eager, graph capture, graph replay).  gsm_sync_demod.m:112-124 per stream."""
+    rng = np.random.default_rng(n_streams)
+    first = 400000 + 2000 * (n_streams % 7)
+    jobs = [(first + i, 61, _mixed_draw(i, rng)) for i in range(n_streams)]
+    raw = np.stack(parity.pool_map(parity.gen_stream_job, jobs, max_workers=128))
+    assert len({r.tobytes()[:2048] for r in raw}) == n_streams
+    orcs = parity.pool_map(parity.oracle_job_safe, [(raw[i], setup["coef"], setup["ts"], FC) for i in range(n_streams)], max_workers=128)
+    n_cal = 0
+    first_table = None
+    for rep in range(3):
+        out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+        det = g.last_batch_details(n_streams)
+        if first_table is None:
+            first_table = out["table"].copy()
+        else:
+            assert np.array_equal(first_table, out["table"], equal_nan=True), f"call {rep} differs from the first"
+        for i in range(n_streams):
+            orc, err = orcs[i]
+            if orc is None:
+                assert out["table"][i, 9] < 0, f"stream {i}: the oracle raised '{err}', gpu status {out['table'][i, 9]}"
+                continue
+            parity.compare_stream(orc, out["table"][i], det, i, out["pos_info"][i])
+            n_cal += rep == 0 and out["table"][i, 9] == 0
+    assert n_cal > n_streams // 2, "most of the mixed draw should calibrate"
+
+
+def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup):
+    """the fused tail (k_post_chain_r: workgroups exchange results INSIDE one launch) with other tenants on the
+    GPU.  Two contexts on two streams, 200 64-stream steps each, enqueued from two host threads, while a third context keeps
+    the CUs busy with 1 600-capture scanner batches: every table identical to the single-context reference, no negative
+    status, bounded wall time; and the library never had two fused tails in flight at once (the later caller of an overlapping
+    pair took the four-launch tail: gsmcal_fused_tail_stats)."""
+    import threading
+    import time
+    distinct = np.stack([g.synth.make_stream(dongle=8200 + d, num_frames=61)[0] for d in range(8)])
+    raw = np.tile(distinct, (8, 1))
+    ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    assert np.all(ref["table"][:, 9] >= 0)
+    n = raw.shape[1] // 2
+    caps = np.stack([g.synth.make_stream(dongle=8300, arfcn=i, num_frames=26, bcch=i % 3 != 2)[0] for i in range(8)])
+    ctxs = [g.Context(0) for _ in range(3)]
+    stop = threading.Event()
+    errs, tables = [], {}
+
+    def calib(k):
+        try:
+            cx = ctxs[k]
+            d_raw, d_tab, d_pos = cx.alloc(raw.nbytes), cx.alloc(64 * g.TABLE_COLS * 8), cx.alloc(64 * 2 * g.MAX_POS_ROWS * 8)
+            cx.h2d(d_raw, raw)
+            cx.sync()
+            got = []
+            for step in range(200):
+                g.calibrate_batch_dev(d_raw, 64, n, setup["coef"], setup["ts"], FC, d_tab, d_pos, ctx=cx)
+                if step % 20 == 19:                                   # twenty steps in flight, then look
+                    cx.sync()
+                    t = np.empty((64, g.TABLE_COLS))
+                    cx.d2h(t, d_tab)
+                    got.append(t)
+            tables[k] = got
+            for p_ in (d_raw, d_tab, d_pos):
+                cx.free(p_)
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    def hog():
+        try:
+            cx = ctxs[2]
+            big = np.tile(caps, (200, 1))
+            while not stop.is_set():
+                g.fcch_scan_batch(big, setup["coef30"], ctx=cx)
+        except Exception as e:  # noqa: BLE001
+            errs.append(("hog", repr(e)))
+
+    th = threading.Thread(target=hog)
+    th.start()
+    t0 = time.time()
+    workers = [threading.Thread(target=calib, args=(k,)) for k in range(2)]
+    for w_ in workers:
+        w_.start()
+    for w_ in workers:
+        w_.join(timeout=300)
+    wall = time.time() - t0
+    stop.set()
+    th.join(timeout=120)
+    stats = [cx.fused_tail_stats() for cx in ctxs[:2]]
+    for cx in ctxs:
+        cx.close()
+    assert not errs, errs
+    assert not any(w_.is_alive() for w_ in workers) and wall < 120.0, f"two contexts beside a CU hog took {wall:.1f} s"
+    for k in range(2):
+        assert len(tables[k]) == 10
+        for t in tables[k]:
+            assert np.array_equal(t, ref["table"], equal_nan=True), f"context {k}: table differs from the single-context reference"
+            assert np.all(t[:, 9] >= 0)
+    fused, fell = sum(s_[0] for s_ in stats), sum(s_[1] for s_ in stats)
+    assert fused + fell == 400 and fused >= 1, stats
+    print(f"two contexts + hog: {wall:.2f} s, fused launches {stats[0][0]} + {stats[1][0]}, gate fall-backs {stats[0][1]} + {stats[1][1]}")
 
 
 def test_large_batches_take_the_throughput_paths(g, setup):
