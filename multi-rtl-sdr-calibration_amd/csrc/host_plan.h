@@ -81,12 +81,14 @@ struct gsmcal_ctx {
     double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
     bool fuse_fine_gather = true;   // GSMCAL_FUSE_GATHER=0: a k_gather launch writes the fine windows, k_fine_cert reads them back
-    // fused tail bookkeeping (fused_gate): streams whose fused tail this context has enqueued / the GPU has finished (pinned
-    // host word, += 1 by workgroup 0 of every stream at the end of k_post_chain_r)
-    unsigned long long fused_expected = 0;
-    unsigned long long* fused_done = nullptr;
+    // fused tail bookkeeping (fused_gate), per stream index of lane 0: fused tails this context has enqueued over the stream /
+    // the launch count workgroup 0 of the stream stored at the end of its last k_post_chain_r (pinned host words)
+    static constexpr int FUSED_MAX_STREAMS = 1024;
+    std::vector<unsigned> fused_expected;
+    unsigned* fused_done = nullptr;
+    int fused_hi = 0;               // streams [0, fused_hi) may have a fused tail in flight
     unsigned long long n_fused_launches = 0, n_gate_fallbacks = 0;   // gsmcal_fused_tail_stats
-    int capture_fused_streams = 0;  // streams of fused tails enqueued during the stream capture in progress
+    int capture_fused_streams = 0;  // streams of the fused tail enqueued during the stream capture in progress
     int lane_stagger = -1;          // GSMCAL_LANE_STAGGER=0/1: calibration lanes start together / one front kernel apart; -1 (default): apart from 256 streams per lane on
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool fcert_s47 = true;          // GSMCAL_FCERT_S47=0: k_fine_cert builds its windows with the LDS-tap FIR loop also for the 47-tap symmetric filter
@@ -355,8 +357,10 @@ struct FusedGate { std::mutex mu; std::vector<gsmcal_ctx*> ctxs; };
 inline FusedGate& fused_gate() { static FusedGate g; return g; }
 
 void fused_gate_register(gsmcal_ctx* c) {
-    if (hipHostMalloc((void**)&c->fused_done, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->fused_done = nullptr; }
-    if (c->fused_done) *c->fused_done = 0;
+    const size_t bytes = (size_t)gsmcal_ctx::FUSED_MAX_STREAMS * sizeof(unsigned);
+    if (hipHostMalloc((void**)&c->fused_done, bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->fused_done = nullptr; }
+    if (c->fused_done) memset(c->fused_done, 0, bytes);
+    c->fused_expected.assign(gsmcal_ctx::FUSED_MAX_STREAMS, 0u);
     std::lock_guard<std::mutex> lk(fused_gate().mu);
     fused_gate().ctxs.push_back(c);
 }
@@ -371,14 +375,39 @@ void fused_gate_unregister(gsmcal_ctx* c) {
     c->fused_done = nullptr;
 }
 
-bool fused_busy(const gsmcal_ctx* o) {
-    return o->fused_done && o->fused_expected != *(volatile unsigned long long*)o->fused_done;
+// (the launch counters on the device were re-created, all zero: the host's view follows -- called with the device idle)
+void fused_gate_reset(gsmcal_ctx* c) {
+    std::lock_guard<std::mutex> lk(fused_gate().mu);
+    if (c->fused_done) memset(c->fused_done, 0, (size_t)gsmcal_ctx::FUSED_MAX_STREAMS * sizeof(unsigned));
+    c->fused_expected.assign(gsmcal_ctx::FUSED_MAX_STREAMS, 0u);
+    c->fused_hi = 0;
 }
 
-// May context c enqueue a fused tail over `streams` streams now?  true: counted as enqueued.  false: take the four-launch tail.
+// (gate mutex held) does context o have a fused tail enqueued that the GPU has not finished?
+bool fused_busy(gsmcal_ctx* o) {
+    if (!o->fused_done) return false;
+    const volatile unsigned* d = o->fused_done;
+    while (o->fused_hi > 0 && d[o->fused_hi - 1] == o->fused_expected[o->fused_hi - 1]) --o->fused_hi;   // (streams finish in any order: trim from the top)
+    for (int s = 0; s < o->fused_hi; ++s)
+        if (d[s] != o->fused_expected[s]) return true;
+    o->fused_hi = 0;
+    return false;
+}
+
+// (gate mutex held) may context c enqueue a fused tail over streams [0, streams) now?  true: counted as enqueued.
+bool fused_gate_pass(gsmcal_ctx* c, int streams) {
+    if (!c->fused_done || streams > gsmcal_ctx::FUSED_MAX_STREAMS) return false;   // (no pinned words: the gate cannot see this context -- never fuse)
+    for (gsmcal_ctx* o : fused_gate().ctxs)
+        if (o != c && o->device == c->device && fused_busy(o)) return false;
+    for (int s = 0; s < streams; ++s) ++c->fused_expected[s];
+    if (streams > c->fused_hi) c->fused_hi = streams;
+    ++c->n_fused_launches;
+    return true;
+}
+
+// May context c enqueue a fused tail over `streams` streams now?  false: take the four-launch tail.
 bool fused_gate_enter(gsmcal_ctx* c, int streams) {
-    if (!c->fused_done) return false;                     // (no pinned word: the gate cannot see this context -- never fuse)
-    if (c->capturing) { c->capture_fused_streams += streams; return true; }   // our own capture: run_maybe_graph passes the gate at every replay
+    if (c->capturing) { c->capture_fused_streams = streams; return c->fused_done != nullptr; }   // our own capture: run_maybe_graph passes the gate at every replay
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (c->stream && (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
         (void)hipGetLastError();                          // the CALLER is capturing: the library will not see the replays -- never fuse
@@ -386,11 +415,9 @@ bool fused_gate_enter(gsmcal_ctx* c, int streams) {
         return false;
     }
     std::lock_guard<std::mutex> lk(fused_gate().mu);
-    for (const gsmcal_ctx* o : fused_gate().ctxs)
-        if (o != c && o->device == c->device && fused_busy(o)) { ++c->n_gate_fallbacks; return false; }
-    c->fused_expected += (unsigned long long)streams;
-    ++c->n_fused_launches;
-    return true;
+    const bool ok = fused_gate_pass(c, streams);
+    if (!ok) ++c->n_gate_fallbacks;
+    return ok;
 }
 
 // Workgroups of the fused tail (k_post_chain_r<8,512,47> | k_post_chain_r<0,0,0>) that fit one CU at this dynamic LDS size, from
@@ -512,7 +539,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             const int per_cu = lds <= 159 * 1024 && H <= MAXH ? post_chain_blocks_per_cu(c, variant, lds) : 0;
             chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && per_cu > 0 &&
                            (long)H * S <= (long)per_cu * c->n_cu && c->n_lanes_used == 1;
-            if (chain->fused) chain->fused = fused_gate_enter(c, S);
             if (chain->fused) {
                 // k_post_chain_r's exchange block [S][2 parities][4 stages][MAXH][2] and launch counters [S]: the layout
                 // does not depend on the batch geometry (fixed MAXH stride per sub-block, one counter per stream in a buffer of its
@@ -526,7 +552,11 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                     RET_IF(ensure(c, c->cur->xepoch, need_e));
                     HIPCHK(c, hipMemsetAsync(c->cur->xch.p, 0xFF, c->cur->xch.cap, c->cur->stream));
                     HIPCHK(c, hipMemsetAsync(c->cur->xepoch.p, 0, c->cur->xepoch.cap, c->cur->stream));
+                    fused_gate_reset(c);                      // (ensure() left the device idle: nothing of this context is in flight)
                 }
+                chain->fused = fused_gate_enter(c, S);      // (behind the re-creation above: it resets the gate's view of this context)
+            }
+            if (chain->fused) {
                 PostChainArgs pa;
                 memset(&pa, 0, sizeof(pa));
                 pa.ga1 = gather_args(src, lvl + 1, g.nfft);
@@ -939,10 +969,7 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
             bool ok;
             {
                 std::lock_guard<std::mutex> lk(fused_gate().mu);
-                ok = c->fused_done != nullptr;
-                for (const gsmcal_ctx* o : fused_gate().ctxs)
-                    if (o != c && o->device == c->device && fused_busy(o)) ok = false;
-                if (ok) { c->fused_expected += (unsigned long long)slot.fused_streams; ++c->n_fused_launches; }
+                ok = fused_gate_pass(c, slot.fused_streams);
             }
             if (!ok) return enqueue();
         }

@@ -1061,7 +1061,8 @@ __global__ void __launch_bounds__(FV_THREADS) k_fine_verify(const StreamState* _
 struct PostChainArgs {
     GatherArgs ga1, ga_sch, ga0;       // burst windows at level lvl+1, SCH search windows, post-SCH burst windows
     StepArgs sa;                       // one set of step arguments serves every decision step (NB = 1)
-    unsigned long long* done;          // pinned host word of the context: += 1 per finished stream (gsmcal_ctx::fused_done; nullptr: not counted)
+    unsigned* done;                    // pinned host words of the context, one per stream: the launch count of the stream's last finished
+                                       // fused tail (gsmcal_ctx::fused_done; nullptr: not reported)
     int lvl_fine, lvl_sch, lvl_post;   // input levels of the three reference functions
     int nfft, ov, len_ts, sch_nshift, fine_nshift, H;
     const cplx* tw_g; const cplx* ts;
@@ -1162,7 +1163,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 0);
     // exchange block of stream s: [parity][stage][MAXH][2] -- a layout that does not depend on this launch's H or S, so launches
     // of any geometry (eager, or replayed from graphs captured at different times) can follow each other on one block
-    const unsigned par = epoch[s] & 1u;
+    const unsigned ep = epoch[s], par = ep & 1u;
     constexpr int XST = 2 * MAXH;                                                // granules per stage
     unsigned long long* mine_x = xch + ((size_t)s * 2 + par) * 4 * XST;          // [stage][w][2]
     unsigned long long* other_x = xch + ((size_t)s * 2 + (par ^ 1u)) * 4 * XST;
@@ -1251,9 +1252,10 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
         if (a.with_totals) d_totals(sh, s, a.sa.table, a.sa.pos_info_out, a.sa.r_len_out, lane);
         StateLds::store(sts + s, sh, lane);
         if (lane == 0) {
-            epoch[s] = par + 1u;                                    // (only the parity matters)
-            // the host's gate (one fused tail of the process in flight per device) reads this pinned word: fire and forget
-            if (a.done) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            epoch[s] = ep + 1u;                                     // the stream's launch count (its parity selects the exchange block)
+            // the host's gate (one fused tail of the process in flight per device) reads this pinned word: a plain posted store
+            // like the table row's (one ATOMIC on a shared host word per stream serialises on PCIe: +56 us at 64 streams)
+            if (a.done) __hip_atomic_store(a.done + s, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
