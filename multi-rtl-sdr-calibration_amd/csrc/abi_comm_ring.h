@@ -235,8 +235,7 @@ int gsmcal_allgather_table_async(gsmcal_ctx* c, gsmcal_comm* g, const double* d_
     if (!c->ag_ready[slot]) {
         // device-scope release: the table only has to be visible to the collective's kernel on this device; a default event
         // flushes to system scope at every record (see get_event())
-        unsigned fl = hipEventDisableTiming | hipEventReleaseToDevice;
-        if (const char* e = getenv("GSMCAL_AG_EVENT_FLAGS")) fl = (unsigned)strtoul(e, nullptr, 0);
+        const unsigned fl = hipEventDisableTiming | hipEventReleaseToDevice;     // (no other combination changed the event's cost: NOTES_r04)
         if (hipEventCreateWithFlags(&c->ag_ready[slot], fl) != hipSuccess) {
             (void)hipGetLastError();
             HIPCHK(c, hipEventCreateWithFlags(&c->ag_ready[slot], hipEventDisableTiming));
