@@ -385,8 +385,18 @@ def main():
                 return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode="async" if want == "async" else "inline", stream=stream)
 
         def verify(g):
-            with torch.cuda.device(dev), torch.cuda.stream(stream):
-                gdist.verify_gatherer(g, gsmcal.TABLE_COLS, dev, lambda: stream.synchronize())
+            # BOTH placements the autotune below may switch to, each on a throw-away context and stream of its own: a trial
+            # exchange that hangs leaves that stream stuck and abandoned, never the chain's -- the fall-back to torch's
+            # collective then still has a clean stream to run on
+            with torch.cuda.device(dev):
+                for m in (("async",) if want == "async" else ("inline", "async")):
+                    vstream = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(vstream):
+                        vctx = gsmcal.Context(local_rank, stream=vstream.cuda_stream)
+                        vtg = gdist.NativeTableGatherer(vctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode=m, stream=vstream)
+                        gdist.verify_gatherer(vtg, gsmcal.TABLE_COLS, dev, lambda: vstream.synchronize())
+                        vstream.synchronize()
+                        vctx.close()
 
         tg, gather_kind, gather_fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev), dev,
                                                                  want=want, verify=verify, timeout_s=float(os.environ.get("GSMCAL_BENCH_NATIVE_TIMEOUT_S", "90")))
