@@ -376,12 +376,17 @@ def main():
         # (the native path had only ever run on one rank).  GSMCAL_BENCH_GATHER=torch | native | async skips the choice.
         want = os.environ.get("GSMCAL_BENCH_GATHER", "native")
         holder = {}
+        # the id travels through the process group HERE, on every rank alike: what follows inside make_native / verify touches no
+        # torch collective, so a rank that fails or hangs there cannot put the group's collectives out of step
+        uid = gdist.broadcast_unique_id(ctx, dev) if want != "torch" else None
 
         def make_native():
             if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back)
                 raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
             with torch.cuda.device(dev), torch.cuda.stream(stream):
-                holder["comm"] = gdist.native_comm_from_process_group(ctx, dev)
+                holder["comm"] = gdist.native_comm_from_process_group(ctx, dev, unique_id=uid) if uid is not None else None
+                if holder["comm"] is None:
+                    raise RuntimeError("rank 0 could not draw an RCCL unique id")
                 return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode="async" if want == "async" else "inline", stream=stream)
 
         def verify(g):

@@ -309,17 +309,37 @@ def verify_gatherer(tg, cols, device, sync, timeout_s=60.0):
         tg.work[b] = None
 
 
-def native_comm_from_process_group(ctx, device, group=None):
-    """A NativeComm spanning the ranks of a torch.distributed process group: rank 0 draws the RCCL id, the group broadcasts it
-    (the one use of torch.distributed in the bootstrap), every rank joins with ncclCommInitRank through the C ABI."""
+def broadcast_unique_id(ctx, device, group=None):
+    """Rank 0 draws an RCCL id and the process group broadcasts it: the ONE use of torch.distributed in the native bootstrap.
+    Every rank makes exactly this one collective call whatever happens on rank 0 (a failure there travels as a flag byte), so
+    the group's collective order stays the same on all ranks -- the joining itself (NativeComm) then touches no torch collective
+    and may fail or hang on any one rank without desynchronising the group.  Returns the 128-byte id, or None if rank 0 had none."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    idt = torch.zeros(128, dtype=torch.uint8, device=device)
+    rank = dist.get_rank(group)
+    idt = torch.zeros(129, dtype=torch.uint8, device=device)
     if rank == 0:
-        idt.copy_(torch.frombuffer(bytearray(NativeComm.unique_id(ctx)), dtype=torch.uint8))
+        try:
+            raw = NativeComm.unique_id(ctx)
+            idt[:128].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            idt[128] = 1
+        except Exception:  # noqa: BLE001 - reported to every rank through the flag
+            pass
     dist.broadcast(idt, 0, group=group)
-    return NativeComm(ctx, world, rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
+    host = idt.cpu().numpy()
+    return bytes(host[:128].tobytes()) if int(host[128]) == 1 else None
+
+
+def native_comm_from_process_group(ctx, device, group=None, unique_id=None):
+    """A NativeComm spanning the ranks of a torch.distributed process group: rank 0 draws the RCCL id, the group broadcasts it
+    (broadcast_unique_id; pass `unique_id` when that already happened), every rank joins with ncclCommInitRank through the C ABI."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if unique_id is None:
+        unique_id = broadcast_unique_id(ctx, device, group)
+    if unique_id is None:
+        raise RuntimeError("rank 0 could not draw an RCCL unique id")
+    return NativeComm(ctx, world, rank, unique_id=unique_id)
 
 
 def sampling_phase_difference(pos_info_a, pos_info_b):
