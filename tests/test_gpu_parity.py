@@ -604,12 +604,14 @@ def test_wide_batch_of_distinct_streams_every_row_against_the_oracle(g, setup, n
     assert n_cal > n_streams // 2, "most of the mixed draw should calibrate"
 
 
-def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup):
+@pytest.mark.parametrize("forced_graphs", [False, True])
+def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_graphs):
     """the fused tail (k_post_chain_r: workgroups exchange results INSIDE one launch) with other tenants on the
     GPU.  Two contexts on two streams, 200 64-stream steps each, enqueued from two host threads, while a third context keeps
     the CUs busy with 1 600-capture scanner batches: every table identical to the single-context reference, no negative
     status, bounded wall time; and the library never had two fused tails in flight at once (the later caller of an overlapping
-    pair took the four-launch tail: gsmcal_fused_tail_stats)."""
+    pair took the four-launch tail: gsmcal_fused_tail_stats).  forced_graphs: the same with GSMCAL_GRAPH=2 -- every call replayed
+    from a captured graph whose fused tail passes the gate at each replay (a busy gate sends that call through eager launches)."""
     import threading
     import time
     distinct = np.stack([g.synth.make_stream(dongle=8200 + d, num_frames=61)[0] for d in range(8)])
@@ -618,7 +620,10 @@ def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup):
     assert np.all(ref["table"][:, 9] >= 0)
     n = raw.shape[1] // 2
     caps = np.stack([g.synth.make_stream(dongle=8300, arfcn=i, num_frames=26, bcch=i % 3 != 2)[0] for i in range(8)])
+    if forced_graphs:
+        monkeypatch.setenv("GSMCAL_GRAPH", "2")              # read when a context is created
     ctxs = [g.Context(0) for _ in range(3)]
+    monkeypatch.delenv("GSMCAL_GRAPH", raising=False)
     stop = threading.Event()
     errs, tables = [], {}
 
