@@ -11,7 +11,9 @@ layout under gloo: tests/test_dist_cpu.py).  One process per GPU; runs BOTH coll
   3. the table is gathered (a) by torch.distributed over RCCL (gsmcal.dist.allgather_table and the bench's double-buffered
      TableGatherer), (b) by the native gsmcal_allgather_table, bootstrapped through an id file carrying this launch's
      nonce, with a stale id file of another launch planted at the path first, and (c) by bench.py's current N > 1
-     exchange: NativeTableGatherer (in line and on the side stream) on a communicator bootstrapped through the process group;
+     exchange: NativeTableGatherer (in line and on the side stream) on a communicator bootstrapped through the process group,
+     and (d) through the decisions bench.py takes before its timed loop (gsmcal.dist.choose_gatherer with a checked trial exchange,
+     autotune_placement): every rank must end on the native gatherer and the same placement;
   4. every rank compares all gathered tables, row by row and bit for bit, with the table it computes for ALL units on its
      own GPU (unit independence makes that the expected result), and rank 0 checks unit 0 against the CPU oracle.
 
@@ -139,6 +141,58 @@ def main():
         finally:
             torch.cuda.synchronize(dev)
             comm2.close()
+        # (d) the DECISIONS bench.py takes before its timed loop, on the real communicator: the id through the process group (one
+        # collective on every rank), the native set-up + a checked trial exchange under a time-out, the agreement of the ranks, and
+        # the placement autotune (max over ranks) -- every rank must end on the native gatherer and on the same placement
+        uid = gd.broadcast_unique_id(ctx, dev)
+        held = {}
+
+        def make_native():
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                held["comm"] = gd.native_comm_from_process_group(ctx, dev, unique_id=uid)
+                return gd.NativeTableGatherer(ctx, held["comm"], sizes, gsmcal.TABLE_COLS, dev, stream=stream)
+
+        def verify(g_):
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                gd.verify_gatherer(g_, gsmcal.TABLE_COLS, dev, lambda: torch.cuda.synchronize(dev))
+
+        tg2, kind, why = gd.choose_gatherer(make_native, lambda: gd.TableGatherer(sizes, gsmcal.TABLE_COLS, dev), dev, verify=verify, timeout_s=120.0)
+        assert kind == "native" and why is None, f"choose_gatherer fell back: {why}"
+        try:
+            import time
+
+            def measure(mode):
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                t0 = time.perf_counter()
+                for step in range(8):
+                    b = step & 1
+                    tg2.wait(b)
+                    tg2.post(b, local_t + float(step))
+                for b in (0, 1):
+                    tg2.rows(b)
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / 8
+
+            tune = gd.autotune_placement(tg2, measure, dev)
+            chosen = torch.tensor([0 if tune["chosen"] == "inline" else 1], dtype=torch.int32, device=dev)
+            lo_c, hi_c = chosen.clone(), chosen.clone()
+            dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+            assert int(lo_c.item()) == int(hi_c.item()) and tg2.mode == tune["chosen"], "the ranks disagree on the placement"
+            for step in range(4):
+                b = step & 1
+                tg2.wait(b)
+                tg2.post(b, local_t + float(step))
+            for b in (0, 1):
+                rows = tg2.rows(b)
+                torch.cuda.synchronize(dev)
+                if tg2.mode == "async":
+                    ctx.check(ctx.lib.gsmcal_allgather_sync(ctx.h, b), "gsmcal_allgather_sync")
+                assert np.array_equal(rows.cpu().numpy(), full + float(2 + b), equal_nan=True), f"chosen gatherer ({tg2.mode}) buffer {b}, {num_units} units"
+        finally:
+            torch.cuda.synchronize(dev)
+            held["comm"].close()
         if rank == 0 and num_units == 7:
             from oracle import gsmcal_oracle as oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
