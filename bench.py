@@ -109,6 +109,13 @@ def parse():
     ap.add_argument("--workload", choices=["calib", "scan"], default="calib",
                     help="calib: full FCCH+SCH chain (headline); scan: scanner path of multi_rtl_sdr_gsm_FCCH_scanner.m "
                          "(front end + FCCH_coarse_position + acceptance; use --frames 64 --streams 200)")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="gsmcal_ctx_set_pipeline_depth for the headline loop: consecutive steps in flight inside ONE context (the front end "
+                         "of step i+1 under the tail of step i; every step is the same full chain on its own output buffers).  1 = one "
+                         "step at a time (reported beside the headline as ms_per_step_depth1)")
+    ap.add_argument("--raw-buffers", type=int, default=4,
+                    help="device copies of the raw batch the headline loop takes in turn (4 x 130 MB > the 256 MB Infinity Cache: every "
+                         "raw byte comes from HBM proper, SURVEY 8d); 1 = re-read one buffer (reported as ms_per_step_llc_resident)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU-oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed HIP-event passes (roofline kernel figure, breakdown)")
@@ -162,7 +169,7 @@ def mixed_kwargs(n, seed):
 class Calib:
     """D streams resident in HBM + everything one calibration step needs."""
 
-    def __init__(self, torch, gsmcal, dev, ctx, raw_t, N, mode, coef, ts, fc, zero_copy=True):
+    def __init__(self, torch, gsmcal, dev, ctx, raw_t, N, mode, coef, ts, fc, zero_copy=True, nbuf=2, nraw=1):
         # zero_copy: the library's last kernel stores the table straight into pinned host memory (the C ABI takes any
         # device-accessible pointer for its outputs), so the step ends with the table on the host and no copy is queued;
         # off for the RCCL path, whose all-gather reads the table from device memory
@@ -172,24 +179,29 @@ class Calib:
         self.coef, self.ts = coef, ts
         self.cf = np.full(self.D, fc)
         D = self.D
-        self.table_t = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(2)]
-        self.pos_t = torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev)
-        self.rlen_t = torch.zeros((D,), dtype=torch.int64, device=dev)
+        # nbuf output sets (table, pos_info, r_len): consecutive steps of a pipelined loop write distinct ones; nraw device copies
+        # of the raw batch taken in turn (the headline: more bytes than the Infinity Cache holds)
+        self.nbuf = nbuf
+        self.table_t = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        self.pos_ts = [torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        self.rlen_ts = [torch.zeros((D,), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+        self.pos_t, self.rlen_t = self.pos_ts[0], self.rlen_ts[0]
         self.r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if mode == "stream" else None
-        self.host_table = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)]
+        self.host_table = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(nbuf)]
+        self.raws = [raw_t] + [raw_t.clone() for _ in range(nraw - 1)]
         dp = gsmcal._lib.c_double_p
         self._p = (coef.ctypes.data_as(dp), ts.ctypes.data_as(dp), self.cf.ctypes.data_as(dp))
 
-    def launch(self, b=0, d=None):
-        """enqueue one calibration pass over the first d streams into table buffer b"""
+    def launch(self, b=0, d=None, r=0):
+        """enqueue one calibration pass over the first d streams of raw buffer r into output set b"""
         ctx, lib = self.ctx, self.ctx.lib
         cp, tp, fp = self._p
-        rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(self.raw_t.data_ptr()), self.D if d is None else d, self.N,
+        rc = lib.gsmcal_calibrate_batch_dev(ctx.h, C.c_void_p(self.raws[r].data_ptr()), self.D if d is None else d, self.N,
                                             cp, len(self.coef), tp, len(self.ts), fp,
                                             C.c_void_p((self.host_table[b] if self.zero_copy else self.table_t[b]).data_ptr()),
-                                            C.c_void_p(self.pos_t.data_ptr()),
+                                            C.c_void_p(self.pos_ts[b].data_ptr()),
                                             C.c_void_p(self.r_t.data_ptr()) if self.r_t is not None else None,
-                                            C.c_void_p(self.rlen_t.data_ptr()))
+                                            C.c_void_p(self.rlen_ts[b].data_ptr()))
         ctx.check(rc, "gsmcal_calibrate_batch_dev")
 
     def to_host(self, b=0):
@@ -361,7 +373,9 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
-    cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc, zero_copy=not use_dist)
+    NBUF = 4
+    nraw = max(1, args.raw_buffers)
+    cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc, zero_copy=not use_dist, nbuf=NBUF, nraw=nraw)
 
     # The all-gather of step i overlaps the kernels of step i+1: the library writes its table alternately into one of
     # two buffers (it keeps a replay graph for each), RCCL gathers from the one just written, and the only wait is
@@ -408,23 +422,33 @@ def main():
         ncomm = holder.get("comm") if gather_kind != "torch" else None
     host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
+    loop = {"nraw": nraw}
+    # Steps in flight inside the one context (gsmcal_ctx_set_pipeline_depth): each step is the same full chain, on output set
+    # k mod 4 and raw buffer k mod nraw; step k's table is complete when step k + depth is enqueued or at the fence.  With torch's
+    # collective (it runs on torch's stream, not behind the call's last stage) or uneven shards (torch pad copies) the depth stays 1.
+    depth = max(1, min(4, args.pipeline_depth))
+    if args.mode != "table" or (use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes))):
+        depth = 1
+    ctx.set_pipeline_depth(depth)
 
     def step():
-        b = (nstep[0] & 1) if use_dist else 0
+        k = nstep[0]
         nstep[0] += 1
+        b, g = k % NBUF, k & 1
         if use_dist:
-            tg.wait(b)
-        cal.launch(b)
+            tg.wait(g)
+        cal.launch(b, r=k % loop["nraw"])
         if use_dist:
-            tg.post(b, cal.table_t[b])                               # one RCCL all-gather of the ppm table
+            tg.post(g, cal.table_t[b])                               # one RCCL all-gather of the ppm table
         else:
             cal.to_host(b)
 
     def fence():
+        ctx.sync()                                                   # (joins the steps still in flight on the library's stage streams)
         if use_dist:
-            for b in range(2):
-                if tg.work[b] is not None:
-                    host_gath[b].copy_(tg.rows(b), non_blocking=True)   # gathered table to the host (every rank)
+            for g in range(2):
+                if tg.work[g] is not None:
+                    host_gath[g].copy_(tg.rows(g), non_blocking=True)   # gathered table to the host (every rank)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -454,8 +478,35 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0].item())
         elapsed_cold = float(tt[1].item()) if elapsed_cold is not None else None
-    last = ((nstep[0] - 1) & 1) if use_dist else 0
-    table = cal.table(last).numpy().copy()
+    last_b = (nstep[0] - 1) % NBUF
+    last = (nstep[0] - 1) & 1                                        # (gather buffer pair of the last step)
+    table = cal.table(last_b).numpy().copy()
+    # every output set of the loop holds the same table: the steps in flight did not disturb each other
+    tables_identical = all(bool(np.array_equal(cal.table(b).numpy(), table, equal_nan=True)) for b in range(min(NBUF, nstep[0])))
+    # ... and the same K steps (a) one at a time, (b) on ONE raw buffer (which the Infinity Cache then serves), single rank only
+    variants = {}
+    if not use_dist and args.mode == "table" and os.environ.get("GSMCAL_BENCH_NO_VARIANTS") != "1":     # (=1: profiler passes that want the headline loop last)
+        def timed_variant(d_, nraw_):
+            ctx.set_pipeline_depth(d_)
+            loop["nraw"] = nraw_
+            nstep[0] = 0
+            t_ = time_steps(torch, dev, step, args.steps, args.warmup, fence, prewarm_s=SUB_PREWARM_S)
+            same_ = all(bool(np.array_equal(cal.table(b).numpy(), table, equal_nan=True)) for b in range(NBUF))
+            return round(1e3 * t_ / args.steps, 4), same_
+        if depth > 1:
+            variants["ms_per_step_depth1"], s1 = timed_variant(1, nraw)
+            tables_identical = tables_identical and s1
+        if nraw > 1:
+            variants["ms_per_step_llc_resident"], s2 = timed_variant(depth, 1)
+            tables_identical = tables_identical and s2
+            if depth > 1:
+                variants["ms_per_step_llc_resident_depth1"], s3 = timed_variant(1, 1)
+                tables_identical = tables_identical and s3
+        loop["nraw"] = nraw
+    ctx.set_pipeline_depth(1)                                        # everything below (checks, event passes, sub-results): one call at a time
+    cal.launch(last_b, r=0)
+    ctx.sync()
+    assert np.array_equal(cal.table(last_b).numpy(), table, equal_nan=True)
 
     # ---- every rank checks rows of its OWN shard against the CPU oracle before anything is reported, whatever the
     # flags (the check used to ride on the CPU-baseline leg) ----
@@ -463,7 +514,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
     det = gsmcal.last_batch_details(min(D, nd), ctx=ctx)
-    pos_host = cal.pos_t.cpu().numpy()
+    pos_host = cal.pos_ts[last_b].cpu().numpy()
     n_rank_checked = 0
     orc_rows = {}
     for i in range(min(nd, 4)):
@@ -499,6 +550,12 @@ def main():
         "value": round(value, 3), "unit": "Msample/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "prewarm_steps": args.prewarm_steps,
         "ms_per_step_no_prewarm": round(1e3 * (elapsed_cold if elapsed_cold is not None else elapsed) / args.steps, 4),
+        "ms_per_step_no_prewarm_what": "the same W + K steps, timed FIRST (before the pre-warm steps" + (" and before the placement autotune: "
+                                       "collective in line" if use_dist else "") + "); the headline follows W + K + prewarm_steps earlier steps",
+        "pipeline_depth": depth,
+        "input": (f"rotated over {nraw} buffers ({nraw} x {D * 2 * N / 1e6:.1f} MB: beyond the 256 MB Infinity Cache, every raw byte from HBM)"
+                  if nraw > 1 else "one raw buffer re-read every step (served by the Infinity Cache)"),
+        "tables_identical": tables_identical, **variants,
         "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64",
         "data": f"synthetic 8x-oversampled GSM BCCH-carrier uint8 IQ (seed {synth.DEFAULT_SEED}); {nd} distinct "
@@ -527,7 +584,15 @@ def main():
                         "kernel; the rest of the chain works on a few KB per burst and is latency-bound (DESIGN.md 4)"}
         # ---- HIP-event passes (untimed): the same K steps again with events on every kernel ----
         if not args.no_kernel_events:
-            prof = event_pass(ctx, lambda: cal.launch(0), args.steps, torch, dev)
+            kk = [0]
+
+            def ev_step():                                   # one call at a time (events on every dispatch), raw buffers in turn like the headline
+                cal.launch(0, r=kk[0] % nraw)
+                kk[0] += 1
+            for _ in range(2 * nraw):
+                ev_step()
+            prof = event_pass(ctx, ev_step, args.steps, torch, dev)
+            prof_llc = event_pass(ctx, lambda: cal.launch(0), args.steps, torch, dev) if nraw > 1 else None
             if prof:
                 tot = {k: v[0] for k, v in prof.items()}
                 dom = max(tot, key=tot.get)
@@ -547,7 +612,13 @@ def main():
                                       "share_of_step_time": round(tot[k] / sum(tot.values()), 3),
                                       "traffic": traffic, "traffic_source": src,
                                       "what": "the one HBM-streaming kernel: 2 B/sample raw read + 16/64 B/sample decimated write; "
-                                              "HIP events on its own dispatch, second run of the same K steps"}
+                                              "HIP events on its own dispatch, second run of the same K steps (one call at a time, raw "
+                                              f"batch rotated over {nraw} device buffers like the headline: HBM proper)"}
+                    if prof_llc and k in prof_llc and prof_llc[k][1]:
+                        avg2 = prof_llc[k][0] / prof_llc[k][1]
+                        roof["kernel"]["avg_launch_ms_llc_resident"] = round(avg2, 5)
+                        roof["kernel"]["achieved_llc_resident"] = round(per_launch / 1e9 / (avg2 * 1e-3), 1)
+                        roof["kernel"]["frac_llc_resident"] = round(per_launch / 1e9 / (avg2 * 1e-3) / HBM_PEAK_GBS, 4)
                 roof["time_dominant_kernel"] = {"name": dom, "ms_per_step": round(tot[dom] / args.steps, 4),
                                                 "bound": "latency (serial fp64 dependency chains, one to three workgroups per CU)"}
         step_traffic, step_src = pmc_step_traffic(D, N)
@@ -560,19 +631,6 @@ def main():
         out["roofline_compute"] = compute_roofline("calib_64" if Dmax == 64 else f"calib_{Dmax}", Dmax, N, len(coef), elapsed / args.steps, args.mode)
         if world == 1 and not args.no_sub:
             out["sub_results"] = sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mixed_raw, distinct)
-            # The front kernel's HBM figure proper: the headline loop re-reads ONE 130 MB buffer, which the 256 MB
-            # Infinity Cache serves from the second step on; with the batch rotated over four buffers every raw byte comes from
-            # HBM.  roofline.kernel carries THAT launch time; the re-read figure stays beside it as *_llc_resident.
-            rot = out["sub_results"].get("input_rotated_over_4_buffers", {}).get("front_kernel")
-            kern = out["roofline"].get("kernel")
-            if rot and kern:
-                kern["achieved_llc_resident"], kern["frac_llc_resident"], kern["avg_launch_ms_llc_resident"] = kern["achieved"], kern["frac"], kern["avg_launch_ms"]
-                kern["avg_launch_ms"] = rot["avg_launch_ms"]
-                kern["achieved"] = round(kern["algorithmic_bytes_per_launch"] / 1e9 / (rot["avg_launch_ms"] * 1e-3), 1)
-                kern["frac"] = round(kern["achieved"] / HBM_PEAK_GBS, 4)
-                kern["what"] = ("the one HBM-streaming kernel: 2 B/sample raw read + 16/64 B/sample decimated write; HIP events on its own dispatch "
-                                "with the raw batch rotated over four device buffers (520 MB > the 256 MB Infinity Cache: HBM proper); "
-                                "*_llc_resident: the same kernel on the one buffer the headline loop re-reads")
         # ---- CPU baseline: the oracle (fp64 NumPy/SciPy restatement) on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             done, t_cpu, checked = 0, 0.0, 0
@@ -766,38 +824,6 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
             cal.to_host(0)
         t = time_steps(torch, dev, two, K, W, prewarm_s=SUB_PREWARM_S) / K
         sub["config2_two_streams"] = {"streams": 2, "ms_per_call": round(1e3 * t, 4), "Msample_per_s": round(2 * N / t / 1e6, 1)}
-        cal.launch(0)
-        torch.cuda.synchronize(dev)
-    # the headline batch with its input in FOUR device buffers used in turn (4 x 130 MB: more than the 256 MB Infinity Cache), so
-    # that no step finds the raw bytes of an earlier one in a cache -- what a deployment fed by the ingest ring sees
-    if args.mode == "table":
-        try:
-            cals = [cal] + [Calib(torch, gsmcal, dev, ctx, cal.raw_t.clone(), N, "table", coef, ts, fc) for _ in range(3)]
-            kk = [0]
-
-            def rot():
-                c_ = cals[kk[0] & 3]
-                kk[0] += 1
-                c_.launch(0)
-                c_.to_host(0)
-            t = time_steps(torch, dev, rot, K, W + 4, prewarm_s=SUB_PREWARM_S) / K
-            same = all(np.array_equal(c_.table(0).numpy(), cals[0].table(0).numpy(), equal_nan=True) for c_ in cals[1:])
-            v = cal.D * N / t / 1e6
-            sub["input_rotated_over_4_buffers"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1), **path(v),
-                                                   "tables_identical_to_headline": bool(same),
-                                                   "what": "the headline step with the raw batch in four device buffers taken in turn "
-                                                           "(520 MB > the 256 MB Infinity Cache): every raw byte comes from HBM proper"}
-            if not args.no_kernel_events:
-                nev = max(8, K)
-                prof = event_pass(ctx, rot, nev, torch, dev)
-                sub["input_rotated_over_4_buffers"]["kernels_ms_per_step_untimed_pass"] = {k: round(v_[0] / nev, 4) for k, v_ in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-                for k, v_ in prof.items():
-                    if k.startswith("k_front") and v_[1]:
-                        sub["input_rotated_over_4_buffers"]["front_kernel"] = {"name": k, "avg_launch_ms": round(v_[0] / v_[1], 5), "launches": v_[1]}
-            del cals
-            torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001
-            sub["input_rotated_over_4_buffers"] = {"error": repr(e)}
         cal.launch(0)
         torch.cuda.synchronize(dev)
     # the same streams with the corrected stream written (the API's real output, 18 B/sample)

@@ -108,6 +108,19 @@ void gsmcal_ctx_destroy(gsmcal_ctx* ctx);
 int gsmcal_sync(gsmcal_ctx* ctx);
 const char* gsmcal_last_error(gsmcal_ctx* ctx);
 const char* gsmcal_version(void);
+/* Pipelined batch calls (round 6).  gsm_sync_demod.m:107-124 is a serial chain per batch of dongles; a service that calibrates batch
+ * after batch does not need batch i finished before batch i+1 starts.  With depth > 1, gsmcal_calibrate_batch_dev calls that run on
+ * one lane (up to 127 streams) and do not ask for r_correct are cut into stages on internal HIP streams -- the front end and coarse
+ * detector of call i+1 run underneath the fine search and fused tail of call i -- each call in one of `depth` workspaces.
+ *   depth 1 (default): every call is complete in the context's stream order when it returns: the semantics of every earlier release.
+ *   depth D > 1: the outputs of call i (table, pos_info, r_len) are complete in the context's stream order at the start of call
+ *     i+D, or after gsmcal_sync(), or after ANY other entry point of this context (they all join the calls in flight first).  The
+ *     raw bytes and output buffers of call i must stay untouched until then: give D consecutive calls distinct output buffers.
+ *     gsmcal_allgather_table[_async] right behind a pipelined call is enqueued behind THAT call's last stage (the gathered
+ *     table completes where the call's own outputs do).  gsmcal_last_batch_details describes the most recent call.
+ * Results are identical at every depth (same kernels, same order per call).  Returns GSMCAL_E_ARG for depth < 1 or > 4. */
+int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* ctx, int depth);
+int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* ctx);
 /* Diagnostics of the batch path's fused tail (one launch for everything behind the fine search's chunk sweep: its workgroups
  * exchange results inside the launch).  Several contexts may drive one GPU from several host threads; the library lets only one
  * such launch of the process be in flight per device and gives the later caller the four-launch tail (same results).

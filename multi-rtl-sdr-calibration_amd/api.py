@@ -68,6 +68,14 @@ class Context:
     def sync(self):
         self.check(self.lib.gsmcal_sync(self.h), "gsmcal_sync")
 
+    def set_pipeline_depth(self, depth):
+        """gsmcal_ctx_set_pipeline_depth: up to `depth` consecutive single-lane calibrate_batch_dev calls in flight (the front
+        end of call i+1 under the tail of call i); outputs of call i complete at call i+depth or sync().  1 = off."""
+        self.check(self.lib.gsmcal_ctx_set_pipeline_depth(self.h, int(depth)), "gsmcal_ctx_set_pipeline_depth")
+
+    def pipeline_depth(self):
+        return int(self.lib.gsmcal_ctx_get_pipeline_depth(self.h))
+
     def fused_tail_stats(self):
         """(batch calls that took the fused tail, calls the one-fused-tail-per-device gate sent to the four-launch tail)"""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

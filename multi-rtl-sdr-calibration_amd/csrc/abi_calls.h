@@ -14,6 +14,7 @@ void gsmcal_params_default(gsmcal_params* p) {
 
 int gsmcal_set_params(gsmcal_ctx* c, const gsmcal_params* p) {
     if (!c || !p) return GSMCAL_E_ARG;
+    RET_IF(pipe_join(c));
     gsmcal_params d;
     gsmcal_params_default(&d);
     if (p->coarse_mv_factor != d.coarse_mv_factor || p->coarse_max_offset != d.coarse_max_offset ||
@@ -84,7 +85,6 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (const char* e2 = getenv("GSMCAL_SNR_INLINE_KEEP")) c->snr_inline_keep = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_FRONT_NT")) c->front_nt = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_SCAN_SPLIT")) c->scan_split = atoi(e2);
-    if (const char* e2 = getenv("GSMCAL_SNR_INLINE_PIPE")) c->snr_inline_pipe = atoi(e2);
     const char* sst = getenv("GSMCAL_SCAN_STAGES");
     if (sst && atoi(sst) >= 1) c->scan_stages = atoi(sst);
     const char* lm = getenv("GSMCAL_LANE_MIN");
@@ -93,26 +93,19 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (ce) c->certify = atoi(ce) != 0;
     const char* sfe = getenv("GSMCAL_SNR_FULL");
     if (sfe) c->snr_full = atoi(sfe) != 0;
-    const char* rle = getenv("GSMCAL_REUSE_L0");
-    if (rle) c->reuse_l0 = atoi(rle) != 0;
     const char* sse = getenv("GSMCAL_SNR_SCREEN_DB");
     if (sse) c->snr_screen_db = atof(sse);
     const char* fge = getenv("GSMCAL_FUSE_GATHER");
     if (fge) c->fuse_fine_gather = atoi(fge) != 0;
-    const char* lse = getenv("GSMCAL_LANE_STAGGER");
-    if (lse) c->lane_stagger = atoi(lse) != 0 ? 1 : 0;
     const char* fpe = getenv("GSMCAL_FUSE_POST");
     if (fpe) c->fuse_post = atoi(fpe) != 0;
     const char* pse = getenv("GSMCAL_POST_SLOTS");
     if (pse && atoi(pse) >= 1) c->post_slots_cap = atoi(pse);
     const char* pe = getenv("GSMCAL_PRESCREEN");
     if (pe && atoi(pe) == 0) c->prescreen = false;
-    const char* f47 = getenv("GSMCAL_FCERT_S47");
-    if (f47) c->fcert_s47 = atoi(f47) != 0;
-    const char* s47 = getenv("GSMCAL_STREAM_S47");
-    if (s47) c->stream_s47 = atoi(s47) != 0;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
     if (fg && atoi(fg) != 0) c->front_generic = true;
+    if (const char* e2 = getenv("GSMCAL_PIPE_STAGES")) c->pipe_stages = atoi(e2) >= 3 ? 3 : (atoi(e2) <= 1 ? 1 : 2);
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
     if (ge && atoi(ge) == 2) c->graph_always = true;
@@ -139,6 +132,7 @@ int gsmcal_ctx_create(int device_id, gsmcal_ctx** out) {
 void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)pipe_drain(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     fused_gate_unregister(c);
@@ -155,6 +149,19 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         if (L.front_done) (void)hipEventDestroy(L.front_done);
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
     }
+    for (int i = 0; i < gsmcal_ctx::PIPE_MAX_DEPTH; ++i) {
+        Lane& L = c->pipe[i];
+        DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.xch, &L.xepoch};
+        for (DevBuf* b : lb)
+            if (b->p) (void)hipFree(b->p);
+        for (int k = 0; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
+            if (c->pipe_handover[i][k]) (void)hipEventDestroy(c->pipe_handover[i][k]);
+        if (c->side_in[i]) (void)hipEventDestroy(c->side_in[i]);
+        if (c->side_tail[i]) (void)hipEventDestroy(c->side_tail[i]);
+        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
+    }
+    for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
+        if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->ag_stream) (void)hipStreamSynchronize(c->ag_stream);
     for (int i = 0; i < gsmcal_ctx::AG_SLOTS; ++i) {
@@ -182,32 +189,48 @@ int gsmcal_fused_tail_stats(gsmcal_ctx* c, unsigned long long* fused_launches, u
 
 int gsmcal_sync(gsmcal_ctx* c) {
     if (!c) return GSMCAL_E_ARG;
+    RET_IF(pipe_drain(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+
+// ---- pipelined batch calls ----------------------------------------------------------------------------------------
+int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* c, int depth) {
+    if (!c || depth < 1 || depth > gsmcal_ctx::PIPE_MAX_DEPTH) return GSMCAL_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    RET_IF(pipe_drain(c));
+    if (depth > 1) RET_IF(pipe_prepare(c));
+    c->pipe_depth = depth;
+    return 0;
+}
+
+int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* c) { return c ? c->pipe_depth : GSMCAL_E_ARG; }
 
 const char* gsmcal_last_error(gsmcal_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int gsmcal_dev_alloc(gsmcal_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     HIPCHK(c, hipMalloc(dptr, bytes));
     return 0;
 }
 int gsmcal_dev_free(gsmcal_ctx* c, void* dptr) {
     if (!c) return GSMCAL_E_ARG;
+    RET_IF(pipe_drain(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(dptr));
     return 0;
 }
 int gsmcal_memcpy_h2d(gsmcal_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) return GSMCAL_E_ARG;
+    RET_IF(pipe_join(c));
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 int gsmcal_memcpy_d2h(gsmcal_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) return GSMCAL_E_ARG;
+    RET_IF(pipe_join(c));
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -215,6 +238,7 @@ int gsmcal_memcpy_d2h(gsmcal_ctx* c, void* dst, const void* src, size_t bytes) {
 
 int gsmcal_profile_enable(gsmcal_ctx* c, int enable) {
     if (!c) return GSMCAL_E_ARG;
+    RET_IF(pipe_drain(c));
     RET_IF(prof_flush(c));
     c->prof = enable != 0;
     if (c->prof && c->ev_pool.size() < 512) {     // event creation is slow: keep it out of the measured launches
@@ -253,7 +277,7 @@ int gsmcal_profile_get(gsmcal_ctx* c, int cap, const char** names, double* total
 int gsmcal_raw2iq_u8(gsmcal_ctx* c, const uint8_t* a, long rows_2n, int d, double* b) {
     if (!c || !a || !b || rows_2n < 2 || (rows_2n & 1) || d < 1) return GSMCAL_E_ARG;
     const long n = rows_2n / 2;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     RET_IF(ensure(c, c->misc, (size_t)rows_2n * d));
     RET_IF(ensure(c, c->arr_out, (size_t)n * d * sizeof(cplx)));
     HIPCHK(c, hipMemcpyAsync(c->misc.p, a, (size_t)rows_2n * d, hipMemcpyHostToDevice, c->stream));
@@ -288,7 +312,7 @@ int gsmcal_raw2iq(gsmcal_ctx* c, const double* a, long rows_2n, int d, double* b
 // ---- a2 filters ----------------------------------------------------------------------------------
 int gsmcal_filter(gsmcal_ctx* c, const double* coef, int ntaps, const double* s, long n, int d, int decim, double* r) {
     if (!c || !coef || !s || !r || ntaps < 1 || n < 1 || d < 1 || decim < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const long nd = (n + decim - 1) / decim;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_array(c, s, (size_t)n * d));
@@ -313,7 +337,7 @@ int gsmcal_chn_filter_4x(gsmcal_ctx* c, const double* s, long n, int d, const do
 
 // ---- a3..a5 coarse detector -----------------------------------------------------------------------
 static int coarse_api(gsmcal_ctx* c, const double* s, long len, CoarseArgs a, StreamState* out) {
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     RET_IF(upload_array(c, s, (size_t)len));
     std::vector<StreamState> v(1);
     host_init_state(v[0], len);
@@ -404,7 +428,7 @@ int gsmcal_FCCH_fine_correction(gsmcal_ctx* c, const double* s, long len, const 
     if (!c || !s || !base_position || !fcch_pos || !num_pos || len < 1 || num_base < 0 || ov < 1 || cap_pos < 1)
         return GSMCAL_E_ARG;
     if (num_base > MAXH) return GSMCAL_E_CAPACITY;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const Geom g(ov);
     RET_IF(upload_array(c, s, (size_t)len));
     RET_IF(upload_cached(c, c->cf, c->h_cf, &carrier_freq, 1));
@@ -451,7 +475,7 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
     if (!c || !fcch_pos || !sch_ts || !pos_info || !num_rows || num_fcch < 0 || len_ts < 1 || ov < 1 || cap_rows < 1)
         return GSMCAL_E_ARG;
     if (num_fcch > MAXH) return GSMCAL_E_CAPACITY;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const Geom g(ov);
     const bool have_s = s != nullptr && len >= 1;   // r = -1 from a failed fine stage arrives as s = NULL
     if (have_s) RET_IF(upload_array(c, s, (size_t)len));
@@ -504,7 +528,7 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
 int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, const double* pos_info, int rows, int ld,
                                     int ov, double carrier_freq, double* r, long cap_r, long* len_r, double* carrier_ppm) {
     if (!c || !pos_info || rows < 1 || ld < rows || ov < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const Geom g(ov);
     bool all_m1 = true;                       // `if pos_info == -1` is true only if every element is -1
     for (int i = 0; i < rows; ++i) all_m1 = all_m1 && pos_info[i] == -1.0 && pos_info[ld + i] == -1.0;
@@ -546,7 +570,7 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, co
 int gsmcal_SCH_equalise(gsmcal_ctx* c, const double* s, long len, const double* pos_info, int rows, int ld, const double* sch_ts,
                         int len_ts, int ov, double* x_eq, int cap_bursts, int* num_bursts, int* len_fde_ov) {
     if (!c || !pos_info || !sch_ts || !num_bursts || rows < 1 || ld < rows || ov < 1 || len_ts < 1 || cap_bursts < 0) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const int L = (148 + 2 * 8 + 30) * ov, N2 = L / DM_N1;      // SCH_demod.m:22,45,53-55: round(156.25 - 8.25) + 2*8 + 30 symbols
     const int sp_t0 = (8 + 42) * ov;                            // :56 sp_of_training (0-based)
     *num_bursts = 0;
@@ -608,7 +632,7 @@ int gsmcal_total_ppm_calculation(const double* ppm_in, int n, double* ppm_out) {
 int gsmcal_frontend_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
                               int decim, double* d_out) {
     if (!c || !d_raw || !coef || !d_out || d < 1 || n < 1 || ntaps < 1 || decim < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     c->cur = &c->lanes[0];
     c->lanes[0].lo = 0; c->lanes[0].n = d; c->n_lanes_used = 1;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
@@ -621,7 +645,7 @@ int gsmcal_frontend_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n
 int gsmcal_frontend_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, const double* coef, int ntaps, int decim,
                           double* out) {
     if (!c || !raw || !out || d < 1 || n < 1 || decim < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const long nd = (n + decim - 1) / decim;
     RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
     RET_IF(ensure(c, c->arr_out, (size_t)nd * d * sizeof(cplx)));
@@ -635,7 +659,7 @@ int gsmcal_frontend_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, cons
 int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
                                double* d_snr_numhit, double* d_positions, double* d_pos_snr, int* d_counts) {
     if (!c || !d_raw || !coef || !d_snr_numhit || d < 1 || n < 1 || ntaps < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // ..FCCH_scanner.m:43-45
     const long nd = (n + decim - 1) / decim;
     if (hits_capacity(nd, dec_ratio) > MAXH) return GSMCAL_E_CAPACITY;
@@ -676,7 +700,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         acc.positions = d_positions ? d_positions + (size_t)lo * MAXH : nullptr;
         acc.pos_snr = d_pos_snr ? d_pos_snr + (size_t)lo * MAXH : nullptr;
         acc.counts = d_counts ? d_counts + lo : nullptr;
-        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, nl == 1 || (c->snr_inline_pipe && S <= 3 * c->n_cu)));
+        RET_IF(coarse(c, S, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, nl == 1 || S <= 3 * c->n_cu));
         CHECK_LAUNCH(c);
     }
     RET_IF(join_lanes(c, nl));
@@ -692,7 +716,7 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
 int gsmcal_fcch_scan_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, const double* coef, int ntaps, double* snr,
                            double* num_hit, double* positions, double* pos_snr, int* counts) {
     if (!c || !raw || !snr || !num_hit || d < 1 || n < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
     RET_IF(ensure(c, c->snrhit, (size_t)d * (2 + 2 * MAXH) * sizeof(double) + (size_t)d * sizeof(int)));
     HIPCHK(c, hipMemcpyAsync(c->misc.p, raw, (size_t)2 * n * d, hipMemcpyHostToDevice, c->stream));
@@ -722,13 +746,86 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     const long nd = (n + decim - 1) / decim;
     int H = hits_capacity(nd, dec_ratio) + 1;
     if (H > MAXH) return GSMCAL_E_CAPACITY;
+    // Pipelined call (gsmcal_ctx_set_pipeline_depth > 1): table-mode calls that run on one lane.  Anything that would touch
+    // what the calls in flight still read (new taps / training sequence / carrier frequencies, a workspace that must grow, the
+    // twiddle table) joins them into the context's stream first.
+    bool pipelined = c->pipe_depth > 1 && !d_r_correct && !c->prof && c->stream != nullptr && plan_lanes(c, d) == 1;
+    if (pipelined) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); pipelined = false; }
+    }
+    const bool same_inputs = (int)c->h_coef.size() == ntaps && memcmp(c->h_coef.data(), coef, (size_t)ntaps * sizeof(double)) == 0 &&
+                             c->h_ts.size() == (size_t)2 * len_ts && memcmp(c->h_ts.data(), sch_ts, (size_t)2 * len_ts * sizeof(double)) == 0 &&
+                             (int)c->h_cf.size() == d && memcmp(c->h_cf.data(), carrier_freq, (size_t)d * sizeof(double)) == 0 &&
+                             c->tw_n == g.nfft && c->head_epoch == c->coef_epoch;
+    if (!pipelined || !same_inputs) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
+    c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
     RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));
     RET_IF(ensure_head(c, decim));
     RET_IF(ensure_twiddles(c, g.nfft));
+    if (pipelined) {
+        // slot = workspace of this call; the context's stream first waits for the call that used it `depth` calls ago (that call's
+        // outputs are complete in the context's stream order from here on)
+        RET_IF(pipe_prepare(c));
+        const int slot = (int)(c->pipe_calls % (unsigned long)c->pipe_depth);
+        const int nst = c->pipe_stages;
+        const int last_ev = gsmcal_ctx::PIPE_MAX_STAGES - 1;
+        Lane& L = c->pipe[slot];
+        if (c->pipe_pending[slot]) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[slot][last_ev], 0));
+            c->pipe_pending[slot] = false;
+        }
+        c->cur = &L;
+        c->n_lanes_used = 1;
+        L.lo = 0; L.n = d;
+        if (nst == 1) {
+            // whole calls side by side: this call on the slot's own stream behind whatever the context's stream holds now; its fused
+            // tail behind the previous call's (one in flight)
+            HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream[slot], c->side_in[slot], 0));
+            L.stream = c->side_stream[slot];
+            c->tail_wait = c->side_last_tail >= 0 && c->side_last_tail != slot ? c->side_tail[c->side_last_tail] : nullptr;
+            c->tail_record = c->side_tail[slot];
+        } else {
+            L.stream = c->stream;                                        // ---- stage 0: front end + coarse detector (:107,110,117)
+        }
+        RET_IF(ensure(c, L.dec, (size_t)d * nd * sizeof(cplx)));
+        RET_IF(front_fused(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
+        RET_IF(coarse(c, d, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));
+        if (nst > 1) {
+            HIPCHK(c, hipEventRecord(c->pipe_handover[slot][0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->pipe_stream[1], c->pipe_handover[slot][0], 0));
+            L.stream = c->pipe_stream[1];                                // ---- stage 1: fine search (:118) [+ stage 2: everything behind the chunk sweep]
+        }
+        if (nst >= 3) { c->split_stream = c->pipe_stream[2]; c->split_event = c->pipe_handover[slot][1]; }
+        c->xlane = &c->lanes[0];
+        Source src{SRC_RAW, d_raw, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
+        c->cf_lane = (const double*)c->cf.p;
+        ChainOut co{d_table, d_pos_info, d_r_len, false};
+        int rc = run_fine(c, d, src, 0, g, H, true, 2, len_ts, &co);
+        if (rc >= 0 && !co.fused) {
+            rc = run_sch(c, d, src, 2, g, H, len_ts, true, 3);
+            if (rc >= 0) rc = run_post(c, d, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out);
+        }
+        const hipStream_t out_stream = L.stream;                         // (stage 1's stream, or stage 2's when the call hopped)
+        c->cf_lane = nullptr; c->xlane = nullptr; c->split_stream = nullptr;
+        if (nst == 1 && rc >= 0 && co.fused) c->side_last_tail = slot;
+        c->tail_wait = nullptr; c->tail_record = nullptr;
+        if (hipEventRecord(c->pipe_handover[slot][last_ev], out_stream) != hipSuccess) { c->err = "hipEventRecord (pipeline)"; rc = GSMCAL_E_HIP; }
+        c->pipe_pending[slot] = true;
+        c->pipe_last_slot = slot;
+        c->pipe_last_stages = nst == 1 ? 1 : (out_stream == c->pipe_stream[2] ? 3 : 2);
+        ++c->pipe_calls;
+        c->detail_lane = &L;
+        c->cur = &c->lanes[0];
+        c->last_S = d;
+        if (rc < 0) { (void)pipe_drain(c); return rc; }
+        return 0;
+    }
     // independent streams: split over lanes (HIP streams) so latency-bound stages of one group overlap the
     // compute-bound fine search of another; a repeated call is replayed as one hipGraph
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps, (uintptr_t)len_ts,
@@ -748,7 +845,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         // then follow one another instead of competing, and each runs beside the compute-bound stages of the lanes ahead of it.
         // Measured (round 4, NOTES_r04.md): 128 / 256 / 512 / 1 024 / 2 048 streams 0.345 / 0.562 / 1.002 / 1.807 / 3.629 ms staggered
         // against 0.349 / 0.554 / 1.002 / 1.874 / 3.715 together: worth it from 256 streams per lane on.
-        const bool stagger = nl > 1 && (c->lane_stagger == 1 || (c->lane_stagger < 0 && d / nl >= 256));   // (one decision for all lanes of the call)
+        const bool stagger = nl > 1 && d / nl >= 256;   // (one decision for all lanes of the call)
         if (stagger) {
             if (!L.front_done) HIPCHK(c, hipEventCreateWithFlags(&L.front_done, hipEventDisableTiming));
             if (i > 0) HIPCHK(c, hipStreamWaitEvent(L.stream, c->lanes[i - 1].front_done, 0));
@@ -772,7 +869,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             const size_t tlds = stream_tile_lds(ntaps);
             bool sym = (int)c->h_coef.size() == ntaps;         // exactly mirrored taps (what fir1 returns)
             for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
-            if (ntaps == 47 && sym && c->stream_s47) {          // the drivers' filter: taps in registers, every sample read once
+            if (ntaps == 47 && sym) {                           // the drivers' filter: taps in registers, every sample read once
                 LAUNCH(c, k_stream_tile_s47<ST47_TILE>, dim3((unsigned)((n + (long)ST47_TILE * ST_TPB - 1) / ((long)ST47_TILE * ST_TPB)), S), dim3(ST_THREADS), stream_tile_s47_lds(), (const StreamState*)L.state.p, ta);
                 CHECK_LAUNCH(c);
             } else if (tlds <= 64 * 1024) {
@@ -799,7 +896,7 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
                            const double* sch_ts, int len_ts, const double* carrier_freq, double* table,
                            double* pos_info, double* r_correct, long* r_len) {
     if (!c || !raw || !table || d < 1 || n < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     RET_IF(ensure(c, c->misc, (size_t)2 * n * d));
     RET_IF(ensure(c, c->table, (size_t)d * GSMCAL_TABLE_COLS * sizeof(double)));
     RET_IF(ensure(c, c->posinfo, (size_t)d * 2 * MAXROWS * sizeof(double)));
@@ -809,6 +906,7 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     RET_IF(gsmcal_calibrate_batch_dev(c, (const uint8_t*)c->misc.p, d, n, coef, ntaps, sch_ts, len_ts, carrier_freq,
                                       (double*)c->table.p, (double*)c->posinfo.p,
                                       r_correct ? (double*)c->arr_out.p : nullptr, (long*)c->rlen.p));
+    RET_IF(pipe_join(c));                      // (a pipelined context: the copies below wait for this call like for any other)
     HIPCHK(c, hipMemcpyAsync(table, c->table.p, (size_t)d * GSMCAL_TABLE_COLS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (pos_info)
         HIPCHK(c, hipMemcpyAsync(pos_info, c->posinfo.p, (size_t)d * 2 * MAXROWS * sizeof(double), hipMemcpyDeviceToHost, c->stream));

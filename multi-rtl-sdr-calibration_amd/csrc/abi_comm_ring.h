@@ -68,7 +68,7 @@ int gsmcal_comm_init_rank(gsmcal_ctx* c, const void* idp, int world, int rank, g
     *out = nullptr;
     RcclApi* a = rccl_api();
     if (!a) { c->err = "librccl.so could not be loaded"; return GSMCAL_E_UNSUPPORTED; }
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     ncclUniqueId id;
     memcpy(&id, idp, sizeof(id));
     ncclComm_t comm = nullptr;
@@ -208,11 +208,15 @@ int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local,
     RcclApi* a = rccl_api();
     if (!a) return GSMCAL_E_UNSUPPORTED;
     HIPCHK(c, hipSetDevice(c->device));
-    const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, c->stream);
+    // behind a pipelined batch call the collective rides on the stream that call's table is written on (its last stage), and the
+    // gathered table is complete where the call's own outputs are: `depth` calls later in the context's stream order, or gsmcal_sync
+    const hipStream_t st = pipe_out_stream(c);
+    const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, st);
     if (r != ncclSuccess) {
         c->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
         return GSMCAL_E_HIP;
     }
+    if (st != c->stream) HIPCHK(c, hipEventRecord(c->pipe_handover[c->pipe_last_slot][gsmcal_ctx::PIPE_MAX_STAGES - 1], st));
     return 0;
 }
 
@@ -242,7 +246,7 @@ int gsmcal_allgather_table_async(gsmcal_ctx* c, gsmcal_comm* g, const double* d_
         }
     }
     if (!c->ag_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ag_done[slot], hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ag_ready[slot], c->stream));
+    HIPCHK(c, hipEventRecord(c->ag_ready[slot], pipe_out_stream(c)));   // (behind a pipelined batch call: the stream its table is written on)
     HIPCHK(c, hipStreamWaitEvent(c->ag_stream, c->ag_ready[slot], 0));
     const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, c->ag_stream);
     if (r != ncclSuccess) {
@@ -280,7 +284,7 @@ struct gsmcal_ring {
 int gsmcal_ring_create(gsmcal_ctx* c, size_t batch_bytes, int slots, gsmcal_ring** out) {
     if (!c || !out || batch_bytes < 1 || slots < 2 || slots > 16) return GSMCAL_E_ARG;
     *out = nullptr;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     gsmcal_ring* r = new gsmcal_ring();
     r->c = c; r->bytes = batch_bytes; r->n = slots;
     r->host.assign(slots, nullptr); r->dev.assign(slots, nullptr);
@@ -317,7 +321,7 @@ void* gsmcal_ring_host(gsmcal_ring* r, int slot) { return (r && slot >= 0 && slo
 int gsmcal_ring_submit(gsmcal_ring* r, int slot, size_t bytes) {
     if (!r || slot < 0 || slot >= r->n || bytes > r->bytes) return GSMCAL_E_ARG;
     gsmcal_ctx* c = r->c;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     if (r->has_consumed[slot]) HIPCHK(c, hipStreamWaitEvent(r->copy, r->consumed[slot], 0));   // the device twin is free again
     HIPCHK(c, hipMemcpyAsync(r->dev[slot], r->host[slot], bytes ? bytes : r->bytes, hipMemcpyHostToDevice, r->copy));
     HIPCHK(c, hipEventRecord(r->copied[slot], r->copy));

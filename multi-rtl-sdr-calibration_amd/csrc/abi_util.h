@@ -5,7 +5,7 @@
 int gsmcal_synth_expand_dev(gsmcal_ctx* c, const uint8_t* d_base, int k, long n, uint8_t* d_out, long d, long first_unit,
                             unsigned long long seed) {
     if (!c || !d_base || !d_out || k < 1 || n < 1 || d < 1 || first_unit < 0) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     c->cur = &c->lanes[0];
     for (long lo = 0; lo < d; lo += 32768) {            // grid.y limit
         const long cnt = d - lo < 32768 ? d - lo : 32768;
@@ -21,12 +21,12 @@ int gsmcal_synth_expand_dev(gsmcal_ctx* c, const uint8_t* d_base, int k, long n,
 int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* coarse_snr, double* fine_first,
                               double* fcch_pos, double* sch_first, int* counts) {
     if (!c || d < 1 || d > c->last_S) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<StreamState> v((size_t)c->last_S);
     if (c->n_lanes_used <= 1 && c->lanes[0].n == 0) { c->lanes[0].lo = 0; c->lanes[0].n = c->last_S; }
     for (int i = 0; i < c->n_lanes_used; ++i) {
-        const Lane& L = c->lanes[i];
+        const Lane& L = c->detail_lane ? *c->detail_lane : c->lanes[i];     // (a pipelined call: the workspace of its slot)
         if (L.n <= 0 || L.lo + L.n > c->last_S) continue;
         HIPCHK(c, hipMemcpy(v.data() + L.lo, L.state.p, (size_t)L.n * sizeof(StreamState), hipMemcpyDeviceToHost));
     }
@@ -52,10 +52,10 @@ int gsmcal_last_batch_details(gsmcal_ctx* c, int d, double* coarse_pos, double* 
 
 int gsmcal_last_batch_snr(gsmcal_ctx* c, int stream, double* snr, long cap, long* n_table, long* n_moving) {
     if (!c || stream < 0 || stream >= c->last_S || !snr || cap < 1) return GSMCAL_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < c->n_lanes_used; ++i) {
-        const Lane& L = c->lanes[i];
+        const Lane& L = c->detail_lane ? *c->detail_lane : c->lanes[i];
         if (stream < L.lo || stream >= L.lo + L.n) continue;
         if (L.snr_stride <= 0 && L.snr_nmove > 0) {
             c->err = "the last batch kept no SNR table (throughput batches compute the window SNRs inside the scan kernel; GSMCAL_SNR_INLINE_KEEP=1 writes it out)";
@@ -113,9 +113,11 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
             if (r[0] < t0) t0 = r[0];
             unsigned long long prev = r[0];
             for (int i = 1; i < 16; ++i) {
-                if (!r[i]) continue;
+                if (!r[i] || r[i] < r[0]) continue;          // absent, or left by an earlier launch that used this block's slot
                 if (r[i] > t1) t1 = r[i];
-                ph[i - 1] += (double)(r[i] - prev) / 100.0; ++pc[i - 1];
+                // stamps are numbered by code path, not by time: one taken EARLIER than its predecessor starts a new chain
+                // (no phase is reported across the break -- the unsigned difference used to print as 1.8e17 us)
+                if (r[i] >= prev) { ph[i - 1] += (double)(r[i] - prev) / 100.0; ++pc[i - 1]; }
                 prev = r[i];
             }
         }
@@ -151,7 +153,7 @@ int gsmcal_devtiming_report(gsmcal_ctx* c) {
             double a = 0.0; int n = 0;
             for (int b = 0; b < DEV_STAMP_BLOCKS; ++b) {
                 const unsigned long long* r = &h[((size_t)k * DEV_STAMP_BLOCKS + b) * 16];
-                if (r[0] && r[i]) { a += ((double)r[i] - (double)r[0]) / 100.0; ++n; }
+                if (r[0] && r[i] && r[i] >= r[0]) { a += ((double)r[i] - (double)r[0]) / 100.0; ++n; }
             }
             if (n) fprintf(stderr, " %d:%.1f", i, a / n);
         }

@@ -69,14 +69,11 @@ struct gsmcal_ctx {
     int snr_inline_keep = 0;        // GSMCAL_SNR_INLINE_KEEP=1: ... and still writes the table out (gsmcal_last_batch_snr)
     int front_nt = -1;              // GSMCAL_FRONT_NT: non-temporal raw loads in k_front_fast (-1: by the size of the call, see front_fused())
     size_t call_raw_bytes = 0;      // raw bytes of the batch call in progress
-    int snr_inline_pipe = 1;        // GSMCAL_SNR_INLINE_PIPE=0: the two-kernel detector in the scanner's pipeline stages (the inline form is used there
-                                    // only while a stage's workgroups are all resident at once: 3 per CU)
     int scan_split = 88;            // GSMCAL_SCAN_SPLIT: percent of a pipeline stage's captures in the first of its two front-kernel launches (0: one launch;
                                     // 12 800 captures: 0 / 70 / 80 / 88 / 94 -> 3.64 / 3.58 / 3.525 / 3.515 / 3.57 ms)
     int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
     int lane_min = 64;              // GSMCAL_LANE_MIN: fewest streams a lane is worth forking for
     bool certify = true;            // GSMCAL_CERT=0: no Parseval certificate, every chunk of every window is swept
-    bool reuse_l0 = true;           // GSMCAL_REUSE_L0=0: every per-burst gather filters its raw bytes again
     bool snr_full = true;           // GSMCAL_SNR_FULL=0: the hop walk of FCCH_coarse_position computes its own 16-point spectra
     double snr_screen_db = 5.0;     // GSMCAL_SNR_SCREEN_DB: level below which k_coarse_snr proves windows instead of computing them
                                     // (typical thresholds hit_avg_snr + th sit at 6.5 .. 7.5 dB; ~95 % of the windows are below 5)
@@ -89,12 +86,34 @@ struct gsmcal_ctx {
     int fused_hi = 0;               // streams [0, fused_hi) may have a fused tail in flight
     unsigned long long n_fused_launches = 0, n_gate_fallbacks = 0;   // gsmcal_fused_tail_stats
     int capture_fused_streams = 0;  // streams of the fused tail enqueued during the stream capture in progress
-    int lane_stagger = -1;          // GSMCAL_LANE_STAGGER=0/1: calibration lanes start together / one front kernel apart; -1 (default): apart from 256 streams per lane on
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
-    bool fcert_s47 = true;          // GSMCAL_FCERT_S47=0: k_fine_cert builds its windows with the LDS-tap FIR loop also for the 47-tap symmetric filter
-    bool stream_s47 = true;         // GSMCAL_STREAM_S47=0: the general k_stream_tile also for the 47-tap symmetric filter
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
+    // ---- pipelined batch calls (gsmcal_ctx_set_pipeline_depth; gsm_sync_demod.m:107-124 over consecutive batches) ----
+    // A calibration call on one lane is cut into stages (front end + coarse detector | fine search | fused tail), each stage of
+    // every call on its own HIP stream (stage 0 = the context's stream), consecutive stages of ONE call chained by events: the
+    // front end of call i+1 runs underneath the tail of call i.  Each of the `pipe_depth` calls that may be in flight works in a
+    // workspace of its own (pipe[slot]); all fused tails share lane 0's exchange block and sit on one stream, in call order.
+    static constexpr int PIPE_MAX_DEPTH = 4, PIPE_MAX_STAGES = 3;
+    int pipe_depth = 1;             // 1: a call is complete in stream order when it returns (the semantics of every earlier release)
+    int pipe_stages = 2;            // GSMCAL_PIPE_STAGES: 2 = front | tail, 3 = front | fine search | fused tail
+    Lane pipe[PIPE_MAX_DEPTH];
+    hipStream_t pipe_stream[PIPE_MAX_STAGES] = {nullptr, nullptr, nullptr};   // [0] unused: stage 0 runs on the context's stream
+    hipEvent_t pipe_handover[PIPE_MAX_DEPTH][PIPE_MAX_STAGES] = {};          // [slot][k]: end of stage k of the slot's call
+    bool pipe_pending[PIPE_MAX_DEPTH] = {false, false, false, false};         // the slot's call has not been joined into the context's stream yet
+    unsigned long pipe_calls = 0;
+    int pipe_last_slot = -1;        // slot of the most recent pipelined call, -1: none since the last join
+    int pipe_last_stages = 0;
+    Lane* xlane = nullptr;          // != nullptr: the lane whose exchange block / launch counters the fused tail uses instead of cur's
+    Lane* detail_lane = nullptr;    // the workspace gsmcal_last_batch_details / _snr read (pipelined call), nullptr: lanes[]
+    hipStream_t split_stream = nullptr;   // run_fine(): behind the chunk sweep the call hops to this stream (third pipeline stage)
+    hipEvent_t split_event = nullptr;
+    // GSMCAL_PIPE_STAGES=1: whole calls side by side, call i on internal stream i mod depth; only the fused tails are chained
+    // (tail i+1 waits for tail i: at most one in flight, as the gate demands of separate contexts)
+    hipStream_t side_stream[PIPE_MAX_DEPTH] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_in[PIPE_MAX_DEPTH] = {}, side_tail[PIPE_MAX_DEPTH] = {};
+    hipEvent_t tail_wait = nullptr, tail_record = nullptr;   // run_fine(): events around the fused tail's launch
+    int side_last_tail = -1;              // slot whose fused tail was enqueued last (-1: none pending)
     struct OccEntry { int variant; size_t lds; int blocks; };
     std::vector<OccEntry> occ_cache;  // post_chain_blocks_per_cu()
     int post_slots_cap = 0;           // GSMCAL_POST_SLOTS: upper bound on the fused tail's workgroups per CU (0: the occupancy calculator's figure)
@@ -471,7 +490,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             if ((per + src.ntaps + 14) / 8 + 1 <= fc_thr && fc_stage_bytes(per, src.ntaps) <= avail) {
                 fg.raw = src.raw; fg.raw_stride = src.raw_stride; fg.coef = src.coef; fg.win_out = win;
                 fg.ntaps = src.ntaps; fg.per = per;
-                bool sym = src.ntaps == 47 && (int)c->h_coef.size() == 47 && c->fcert_s47;
+                bool sym = src.ntaps == 47 && (int)c->h_coef.size() == 47;
                 for (int k = 0; sym && k < 23; ++k) sym = c->h_coef[k] == c->h_coef[46 - k];
                 fg.sym47 = sym ? 1 : 0;
                 break;
@@ -480,7 +499,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     }
     if (!fg.raw) RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     // from here on the lane's window buffer holds level 0 of every fine window (nothing later in a batch call writes it)
-    c->cur->win_l0_len = (src.kind == SRC_RAW && lvl == 0 && c->reuse_l0) ? g.fine_wlen : 0;
+    c->cur->win_l0_len = (src.kind == SRC_RAW && lvl == 0) ? g.fine_wlen : 0;
     c->cur->win_l0_H = H;
     StepArgs sa_fine = sa;
     if (c->prescreen) {
@@ -517,6 +536,12 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
         const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) + 15) & ~(size_t)15;
         sa_fine.NB = 1;
+        if (c->split_stream) {      // pipelined call in three stages: everything behind the chunk sweep runs on the third stage's stream
+            HIPCHK(c, hipEventRecord(c->split_event, c->cur->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->split_stream, c->split_event, 0));
+            c->cur->stream = c->split_stream;
+        }
+        Lane* const X = c->xlane ? c->xlane : c->cur;   // (pipelined calls: one exchange block and one set of launch counters for all slots)
         if (chain) {
             // ---- the fused tail of the chain: verify -> bursts -> SCH windows -> post-SCH bursts in one launch ----
             const int wl_sch = g.sch_nshift - 1 + len_ts;
@@ -549,12 +574,12 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 // (S, H), eager or replayed from a graph captured here or by the caller, may follow each other.
                 // Only growth re-creates the pair (all granules EMPTY, all counters zero); ensure() bumps ws_epoch then.
                 const size_t need_x = (size_t)S * 2 * 4 * 2 * MAXH * sizeof(unsigned long long), need_e = (size_t)S * sizeof(unsigned);
-                if (c->cur->xch.cap < need_x || c->cur->xepoch.cap < need_e) {
+                if (X->xch.cap < need_x || X->xepoch.cap < need_e) {
                     if (c->capturing) return GSMCAL_E_HIP;      // (cannot happen: the eager call before a capture sized both)
-                    RET_IF(ensure(c, c->cur->xch, need_x));
-                    RET_IF(ensure(c, c->cur->xepoch, need_e));
-                    HIPCHK(c, hipMemsetAsync(c->cur->xch.p, 0xFF, c->cur->xch.cap, c->cur->stream));
-                    HIPCHK(c, hipMemsetAsync(c->cur->xepoch.p, 0, c->cur->xepoch.cap, c->cur->stream));
+                    RET_IF(ensure(c, X->xch, need_x));
+                    RET_IF(ensure(c, X->xepoch, need_e));
+                    HIPCHK(c, hipMemsetAsync(X->xch.p, 0xFF, X->xch.cap, c->cur->stream));
+                    HIPCHK(c, hipMemsetAsync(X->xepoch.p, 0, X->xepoch.cap, c->cur->stream));
                     fused_gate_reset(c);                      // (ensure() left the device idle: nothing of this context is in flight)
                 }
                 chain->fused = fused_gate_enter(c, S);      // (behind the re-creation above: it resets the gate's view of this context)
@@ -578,9 +603,11 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
                 pa.with_totals = chain->table ? 1 : 0;
                 pa.done = c->fused_done;
-                if (ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, (unsigned*)c->cur->xepoch.p);
-                else LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)c->cur->xch.p, (unsigned*)c->cur->xepoch.p);
+                if (c->tail_wait) HIPCHK(c, hipStreamWaitEvent(c->cur->stream, c->tail_wait, 0));
+                if (ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
+                else LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
                 CHECK_LAUNCH(c);
+                if (c->tail_record) HIPCHK(c, hipEventRecord(c->tail_record, c->cur->stream));
                 return 0;
             }
         }
@@ -946,6 +973,72 @@ int join_lanes(gsmcal_ctx* c, int nl) {
     c->cur = &c->lanes[0];
     return 0;
 }
+
+// ---- pipelined calls: streams, events, joining --------------------------------------------------------------------------
+int pipe_prepare(gsmcal_ctx* c) {
+    for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)   // (default priority: the later stages at the highest priority measured no better, NOTES_r06)
+        if (!c->pipe_stream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
+    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) {
+        if (!c->side_stream[s]) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[s], hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->side_in[s], &c->side_tail[s]})
+            if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+    }
+    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
+        for (int k = 0; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
+            if (!c->pipe_handover[s][k]) {
+                // hand-overs between stages: device-scope release (see get_event()); the end of the last stage also orders
+                // the table row stored in host memory -- a plain event
+                const unsigned fl = k + 1 < gsmcal_ctx::PIPE_MAX_STAGES ? (hipEventDisableTiming | hipEventReleaseToDevice) : hipEventDisableTiming;
+                if (hipEventCreateWithFlags(&c->pipe_handover[s][k], fl) != hipSuccess) {
+                    (void)hipGetLastError();
+                    HIPCHK(c, hipEventCreateWithFlags(&c->pipe_handover[s][k], hipEventDisableTiming));
+                }
+            }
+    return 0;
+}
+
+// The stream the outputs of the most recent batch call are ordered on: the last stage's stream while a pipelined call is
+// pending, else the context's stream.
+hipStream_t pipe_out_stream(gsmcal_ctx* c) {
+    if (c->pipe_last_slot < 0 || !c->pipe_pending[c->pipe_last_slot]) return c->stream;
+    if (c->pipe_last_stages == 1) return c->side_stream[c->pipe_last_slot];
+    return c->pipe_stream[c->pipe_last_stages - 1];
+}
+
+// The context's stream waits for every pipelined call still in flight (GPU-side waits, the host does not block): from here on
+// the context behaves as at depth 1.  Every entry point but the pipelined batch call itself starts with this.
+int pipe_join(gsmcal_ctx* c) {
+    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
+        if (c->pipe_pending[s]) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[s][gsmcal_ctx::PIPE_MAX_STAGES - 1], 0));
+            c->pipe_pending[s] = false;
+        }
+    c->pipe_last_slot = -1;
+    c->side_last_tail = -1;
+    return 0;
+}
+
+// ... and the host waits too (gsmcal_sync, destruction).
+int pipe_drain(gsmcal_ctx* c) {
+    bool any = false;
+    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) any = any || c->pipe_pending[s];
+    if (any) {
+        for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
+            if (c->pipe_stream[k]) HIPCHK(c, hipStreamSynchronize(c->pipe_stream[k]));
+        for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
+            if (c->side_stream[s]) HIPCHK(c, hipStreamSynchronize(c->side_stream[s]));
+    }
+    return pipe_join(c);
+}
+
+#define ENTER(c)                                   \
+    do {                                           \
+        HIPCHK(c, hipSetDevice((c)->device));      \
+        RET_IF(pipe_join(c));                      \
+    } while (0)
 
 // Run `enqueue` (which only enqueues work on the context's streams) eagerly, or -- from the second identical
 // call on -- as a captured hipGraph replayed with one hipGraphLaunch.  The first call runs eagerly so that every

@@ -1036,20 +1036,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         // ---- specific_fft_snr_fix_avg stand-alone ----
         const long lo = a.t_lo, hi = a.t_hi;
         if (hi >= lo) {
-            if (lo < 1 || hi + fft_len - 1 > len) {
+            if (lo < 1) {
                 if (tid == 0) set_status(st, 3, GSMCAL_E_INDEX);
             } else {
-                const long cnt = hi - lo + 1;
+                // the reference's loop (specific_fft_snr_fix_avg.m:10-11) indexes window by window: a hit in a window that fits
+                // returns before a later window would run past the end of s; only a miss up to there is MATLAB's index error
+                const long hi_fit = hi + fft_len - 1 > len ? len - (fft_len - 1) : hi;
+                const long cnt = hi_fit >= lo ? hi_fit - lo + 1 : 0;
                 for (long i = tid; i < cnt; i += 256) snr_s[i] = FFT16 ? window_snr16(s, lo - 1 + i) : window_snr_generic(s, lo - 1 + i, fft_len, tw);
                 __syncthreads();
                 if (tid == 0) {
-                    for (long i = 0; i < cnt; ++i)
+                    bool hit = false;
+                    for (long i = 0; i < cnt && !hit; ++i)
                         if (snr_s[i] - a.avg_snr > th) {
                             st->coarse_hit_flag = 1;
                             st->mv_hit_idx = (double)(lo + i);
                             st->mv_hit_snr = snr_s[i];
-                            break;
+                            hit = true;
                         }
+                    if (!hit && hi_fit < hi) set_status(st, 3, GSMCAL_E_INDEX);
                 }
             }
         }

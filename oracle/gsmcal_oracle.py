@@ -189,11 +189,19 @@ def specific_fft_snr_fix_avg(s, target_set, fft_len, th, avg_snr):
     lo, hi = int(target_set[0]), int(target_set[1])
     if hi < lo:
         return False, -1, math.inf
-    snr_all = _window_snr(_power_spectra(s, lo, hi, fft_len))
-    for k, i in enumerate(range(lo, hi + 1)):
-        snr = float(snr_all[k])
-        if snr - avg_snr > th:
-            return True, i, snr
+    # the reference indexes window by window (:10-11): a hit in a window that fits returns before a later window would run
+    # past the end of s -- only a miss up to there is MATLAB's index error
+    if lo < 1:
+        raise MatlabIndexError("window outside the signal")
+    hi_fit = min(hi, len(s) - (fft_len - 1))
+    if hi_fit >= lo:
+        snr_all = _window_snr(_power_spectra(s, lo, hi_fit, fft_len))
+        for k, i in enumerate(range(lo, hi_fit + 1)):
+            snr = float(snr_all[k])
+            if snr - avg_snr > th:
+                return True, i, snr
+    if hi_fit < hi:
+        raise MatlabIndexError("window outside the signal")
     return False, -1, math.inf
 
 

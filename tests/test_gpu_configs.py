@@ -221,7 +221,7 @@ def test_scanner_pipeline_choices_change_no_bit(g_mod, ctx, monkeypatch, n_sampl
     d_base, d_raw = ctx.alloc(base.nbytes), ctx.alloc(D * 2 * n)
     d_out, d_pos, d_psn, d_cnt = ctx.alloc(D * 16), ctx.alloc(D * H * 8), ctx.alloc(D * H * 8), ctx.alloc(D * 4)
     variants = {"default": {}, "one_stage": {"GSMCAL_SCAN_STAGES": "1"},
-                "two_kernel_detector_unsplit": {"GSMCAL_SNR_INLINE_PIPE": "0", "GSMCAL_SCAN_SPLIT": "0"},
+                "two_kernel_detector_unsplit": {"GSMCAL_SCAN_STAGES": "2", "GSMCAL_SCAN_SPLIT": "0"},   # (1 050 captures per stage: more than one resident round -> k_coarse_snr + k_coarse_scan)
                 "plain_loads_12_stages": {"GSMCAL_FRONT_NT": "0", "GSMCAL_SCAN_STAGES": "12"}}
     made = {}
     try:

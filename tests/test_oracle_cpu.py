@@ -103,11 +103,25 @@ def test_move_fft_incremental_average_and_first_hit():
 
 
 def test_specific_fft_window_bounds_raise_like_matlab():
-    s = np.ones(100, dtype=complex)
+    from oracle import gsmcal_oracle_literal as lit
+    rng = np.random.default_rng(5)
+    s = rng.standard_normal(100) + 1j * rng.standard_normal(100)
     with pytest.raises(o.MatlabIndexError):
         o.specific_fft_snr_fix_avg(s, (0, 5), 16, 10, 0.0)
+    with pytest.raises(o.MatlabIndexError):          # windows 80..85 fit and miss (noise), 86 runs past the end
+        o.specific_fft_snr_fix_avg(s, (80, 90), 16, 10, 50.0)
+    with pytest.raises(IndexError):
+        lit.specific_fft_snr_fix_avg(s, (80, 90), 16, 10, 50.0)
+    # the reference indexes window by window (specific_fft_snr_fix_avg.m:10-11): a hit in a window that fits is returned before
+    # the loop reaches a window that would run past the end -- both restatements agree
+    s2 = s.copy()
+    s2[82:98] += 40 * np.exp(2j * np.pi * 0.125 * np.arange(16))
+    a = o.specific_fft_snr_fix_avg(s2, (80, 90), 16, 10, 0.0)
+    b = lit.specific_fft_snr_fix_avg(s2, (80, 90), 16, 10, 0.0)
+    assert a[0] and b[0] and a[1] == b[1] and 80 <= a[1] <= 85 and abs(a[2] - b[2]) < 1e-9
+    # lo itself out of range: the very first iteration is the index error
     with pytest.raises(o.MatlabIndexError):
-        o.specific_fft_snr_fix_avg(s, (80, 90), 16, 10, 0.0)
+        o.specific_fft_snr_fix_avg(s2, (86, 90), 16, 10, 0.0)
 
 
 def test_total_ppm_calculation():
