@@ -111,8 +111,8 @@ def parse():
                          "(front end + FCCH_coarse_position + acceptance; use --frames 64 --streams 200)")
     ap.add_argument("--pipeline-depth", type=int, default=1,
                     help="gsmcal_ctx_set_pipeline_depth for the headline loop: consecutive steps in flight inside ONE context (the front end "
-                         "of step i+1 under the tail of step i; every step is the same full chain on its own output buffers).  1 = one "
-                         "step at a time (reported beside the headline as ms_per_step_depth1)")
+                         "of step i+1 under the tail of step i; every step is the same full chain on its own output buffers).  1 (default) = one "
+                         "step at a time; the depth-2 figure is reported beside the headline as ms_per_step_pipeline_depth2")
     ap.add_argument("--raw-buffers", type=int, default=4,
                     help="device copies of the raw batch the headline loop takes in turn (4 x 130 MB > the 256 MB Infinity Cache: every "
                          "raw byte comes from HBM proper, SURVEY 8d); 1 = re-read one buffer (reported as ms_per_step_llc_resident)")
@@ -382,44 +382,7 @@ def main():
     # before a buffer is written again two steps later (gsmcal.dist.TableGatherer; uneven shards are padded).
     # N > 1: the C ABI's own all-gather, in line on the chain's stream (GSMCAL_BENCH_GATHER=async: on the library's side stream;
     # =torch: torch.distributed's collective, round 3's path) -- tools/dist_cost.py has what each costs per step on one rank
-    tg, gather_kind, ncomm, gather_fallback = None, "none", None, None
-    if use_dist:
-        # Which collective: decided in gsmcal.dist.choose_gatherer, identically on every rank.  The native communicator is set up
-        # and one CHECKED trial exchange runs on it (both buffer pairs, every peer's block compared), each under a time-out; if
-        # any rank fails or hangs there, ALL ranks fall back to torch.distributed's collective together and the line says so
-        # (the native path had only ever run on one rank).  GSMCAL_BENCH_GATHER=torch | native | async skips the choice.
-        want = os.environ.get("GSMCAL_BENCH_GATHER", "native")
-        holder = {}
-        # the id travels through the process group HERE, on every rank alike: what follows inside make_native / verify touches no
-        # torch collective, so a rank that fails or hangs there cannot put the group's collectives out of step
-        uid = gdist.broadcast_unique_id(ctx, dev) if want != "torch" else None
-
-        def make_native():
-            if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back)
-                raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
-            with torch.cuda.device(dev), torch.cuda.stream(stream):
-                holder["comm"] = gdist.native_comm_from_process_group(ctx, dev, unique_id=uid) if uid is not None else None
-                if holder["comm"] is None:
-                    raise RuntimeError("rank 0 could not draw an RCCL unique id")
-                return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode="async" if want == "async" else "inline", stream=stream)
-
-        def verify(g):
-            # BOTH placements the autotune below may switch to, each on a throw-away context and stream of its own: a trial
-            # exchange that hangs leaves that stream stuck and abandoned, never the chain's -- the fall-back to torch's
-            # collective then still has a clean stream to run on
-            with torch.cuda.device(dev):
-                for m in (("async",) if want == "async" else ("inline", "async")):
-                    vstream = torch.cuda.Stream(device=dev)
-                    with torch.cuda.stream(vstream):
-                        vctx = gsmcal.Context(local_rank, stream=vstream.cuda_stream)
-                        vtg = gdist.NativeTableGatherer(vctx, holder["comm"], sizes, gsmcal.TABLE_COLS, dev, mode=m, stream=vstream)
-                        gdist.verify_gatherer(vtg, gsmcal.TABLE_COLS, dev, lambda: vstream.synchronize())
-                        vstream.synchronize()
-                        vctx.close()
-
-        tg, gather_kind, gather_fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, gsmcal.TABLE_COLS, dev), dev,
-                                                                 want=want, verify=verify, timeout_s=float(os.environ.get("GSMCAL_BENCH_NATIVE_TIMEOUT_S", "90")))
-        ncomm = holder.get("comm") if gather_kind != "torch" else None
+    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, gsmcal.TABLE_COLS) if use_dist else (None, "none", None, None)
     host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     nstep = [0]
     loop = {"nraw": nraw}
@@ -496,12 +459,15 @@ def main():
         if depth > 1:
             variants["ms_per_step_depth1"], s1 = timed_variant(1, nraw)
             tables_identical = tables_identical and s1
+        else:
+            # two consecutive steps in flight inside the one context (gsmcal_ctx_set_pipeline_depth(2): front end of step i+1 on the
+            # context's stream, fine search + fused tail of step i on an internal stream) -- opt-in: measured within a few per cent
+            # of one step at a time (the fused tail and the fine search each fill the chip's registers and LDS: NOTES_r06)
+            variants["ms_per_step_pipeline_depth2"], s1 = timed_variant(2, nraw)
+            tables_identical = tables_identical and s1
         if nraw > 1:
             variants["ms_per_step_llc_resident"], s2 = timed_variant(depth, 1)
             tables_identical = tables_identical and s2
-            if depth > 1:
-                variants["ms_per_step_llc_resident_depth1"], s3 = timed_variant(1, 1)
-                tables_identical = tables_identical and s3
         loop["nraw"] = nraw
     ctx.set_pipeline_depth(1)                                        # everything below (checks, event passes, sub-results): one call at a time
     cal.launch(last_b, r=0)
@@ -525,19 +491,9 @@ def main():
     if use_dist:
         # the collective's result, checked against what every rank says it sent: digests of the local tables travel
         # through a second, independent group (gloo over TCP), and each rank compares every peer's block of the
-        # RCCL-gathered table with that peer's digest -- not only its own rows
-        import hashlib
-        assert host_gath[last].shape[0] == sum(sizes)
-        mine = hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest()
+        # RCCL-gathered table with that peer's digest -- not only its own rows (gsmcal.dist.check_gathered_table)
         chk = dist.new_group(backend="gloo")
-        digests = [None] * world
-        dist.all_gather_object(digests, mine, group=chk)
-        g_all = host_gath[last].numpy()
-        off = 0
-        for r in range(world):
-            blk = np.ascontiguousarray(g_all[off: off + sizes[r]])
-            assert hashlib.sha256(blk.tobytes()).hexdigest() == digests[r], f"rank {rank}: rank {r}'s rows in the gathered table differ from what it sent"
-            off += sizes[r]
+        gdist.check_gathered_table(host_gath[last].numpy(), table, sizes, rank, group=chk)
         assert np.array_equal(tg.own_rows(last).cpu().numpy(), table, equal_nan=True), "all-gathered table differs from this rank's rows"
         gathered_ok = True
 
@@ -566,9 +522,7 @@ def main():
                                f"({frames} frames), fir1(46), FCCH+SCH+total_ppm_calculation, table on the host",
                    "streams_per_gpu": Dmax, "streams_total": sum(sizes), "samples_per_stream": N, "output": args.mode,
                    "bytes_per_sample_algorithmic": bps,
-                   "collective": {"none": "none", "native": "all_gather(table): gsmcal_allgather_table (native RCCL) in line on the chain's stream",
-                                  "async": "all_gather(table): gsmcal_allgather_table_async (native RCCL on a side stream)",
-                                  "torch": "all_gather(table): torch.distributed over RCCL"}.get(gather_kind, gather_kind),
+                   "collective": COLLECTIVE_NAMES.get(gather_kind, gather_kind),
                    "streams_calibrated_ok": n_ok, "rows_checked_vs_oracle_per_rank": n_rank_checked,
                    "gathered_table_checked_against_every_rank": gathered_ok},
     }
@@ -668,17 +622,76 @@ def main():
             out["parity_checked_streams"] = n_rank_checked
         print(json.dumps(out))
     if use_dist:
-        if gather_fallback and "TimeoutError" in gather_fallback:
-            # a helper thread of choose_gatherer is still stuck inside the abandoned native bootstrap / trial exchange: tearing the
-            # communicators down under it aborts the process after all work is done and reported -- leave without the tear-down
-            dist.barrier()
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(0)
-        if ncomm is not None:
-            torch.cuda.synchronize(dev)
-            ncomm.close()
-        dist.destroy_process_group()
+        finish_dist(torch, dist, gdist, dev, ncomm, gather_fallback)
+
+
+COLLECTIVE_NAMES = {"none": "none", "native": "all_gather(table): gsmcal_allgather_table (native RCCL) in line on the chain's stream",
+                    "async": "all_gather(table): gsmcal_allgather_table_async (native RCCL on a side stream)",
+                    "torch": "all_gather(table): torch.distributed over RCCL"}
+
+
+def setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, cols):
+    """The table gatherer of an N > 1 run, for either workload (calibration table: 10 columns; scanner table: snr, num_hit).
+    Which collective: decided in gsmcal.dist.choose_gatherer, identically on every rank.  The native communicator is set up
+    and one CHECKED trial exchange runs on it (both buffer pairs, every peer's block compared), each under a time-out; if
+    any rank fails or hangs there, ALL ranks fall back to torch.distributed's collective together and the line says so
+    (the native path had only ever run on one rank).  GSMCAL_BENCH_GATHER=torch | native | async skips the choice.
+    Returns (gatherer, kind, native communicator or None, fall-back reason or None)."""
+    want = os.environ.get("GSMCAL_BENCH_GATHER", "native")
+    holder = {}
+    # the id travels through the process group HERE, on every rank alike: what follows inside make_native / verify touches no
+    # torch collective, so a rank that fails or hangs there cannot put the group's collectives out of step
+    uid = gdist.broadcast_unique_id(ctx, dev) if want != "torch" else None
+
+    def make_native():
+        if os.environ.get("GSMCAL_BENCH_FAIL_NATIVE") == "1":     # (test hook for the fall-back)
+            raise RuntimeError("GSMCAL_BENCH_FAIL_NATIVE=1")
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
+            holder["comm"] = gdist.native_comm_from_process_group(ctx, dev, unique_id=uid) if uid is not None else None
+            if holder["comm"] is None:
+                raise RuntimeError("rank 0 could not draw an RCCL unique id")
+            return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, cols, dev, mode="async" if want == "async" else "inline", stream=stream)
+
+    def verify(g):
+        # BOTH placements the autotune may switch to, each on a throw-away context and stream of its own: a trial
+        # exchange that hangs leaves that stream stuck and abandoned, never the chain's -- the fall-back to torch's
+        # collective then still has a clean stream to run on
+        with torch.cuda.device(dev):
+            for m in (("async",) if want == "async" else ("inline", "async")):
+                vstream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(vstream):
+                    vctx = gsmcal.Context(local_rank, stream=vstream.cuda_stream)
+                    vtg = gdist.NativeTableGatherer(vctx, holder["comm"], sizes, cols, dev, mode=m, stream=vstream)
+                    gdist.verify_gatherer(vtg, cols, dev, lambda: vstream.synchronize())
+                    vstream.synchronize()
+                    vctx.close()
+
+    tg, kind, fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, cols, dev), dev,
+                                               want=want, verify=verify, timeout_s=float(os.environ.get("GSMCAL_BENCH_NATIVE_TIMEOUT_S", "90")))
+    return tg, kind, (holder.get("comm") if kind != "torch" else None), fallback
+
+
+def finish_dist(torch, dist, gdist, dev, ncomm, gather_fallback):
+    """Tear-down of an N > 1 run, the same branch on EVERY rank: whether any rank's helper thread is still stuck inside
+    an abandoned native bootstrap / trial exchange is agreed by one all-reduce; then every rank joins ONE barrier; only the
+    ranks with a stuck thread leave without the tear-down (destroying the communicators under that thread aborts the process
+    after all work is done and reported), the others tear down normally."""
+    stuck = bool(gather_fallback and "TimeoutError" in gather_fallback)
+    any_stuck = gdist.all_max(1.0 if stuck else 0.0, dev) > 0.0
+    dist.barrier()
+    if stuck:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    if ncomm is not None:
+        torch.cuda.synchronize(dev)
+        ncomm.close()
+    if any_stuck:
+        # a peer left without destroying its end of the group: a collective tear-down would wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    dist.destroy_process_group()
 
 
 def event_pass(ctx, fn, steps, torch, dev, filt=None):
@@ -962,8 +975,13 @@ def bench_ingest(torch, gsmcal, dev, ctx, D=256, nbatch=8):
             "note": "host-resident input: the path is PCIe-bound; this figure is never `value` (inputs resident in HBM)"}
 
 
-def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup, cpu=True, use_dist=False, world=1, rank=0):
-    """Scanner path (BASELINE configs 3/5): D captures resident in HBM -> snr, num_hit per capture on the host."""
+def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup, cpu=True, use_dist=False, world=1, rank=0,
+               sizes=None, tg=None, first_unit=None):
+    """Scanner path (BASELINE configs 3/5): D captures resident in HBM -> snr, num_hit per capture on the host.
+    N > 1 (multi_rtl_sdr_gsm_FCCH_scanner.m:60-65,163-186: the ARFCN split across dongles and the one table every rank needs):
+    `sizes` = captures per rank, `tg` = the table gatherer (2 columns: snr, num_hit), `first_unit` = this rank's first global
+    capture index; each step ends with ONE all-gather of the (snr, num_hit) table, the GATHERED table goes to the host and is
+    digest-checked against every rank's own rows (gsmcal.dist.check_gathered_table), as in the calibration workload."""
     import torch.distributed as dist
 
     from gsmcal import synth
@@ -976,43 +994,70 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
     raw_t = torch.empty((D, 2 * N), dtype=torch.uint8, device=dev)
     # distinct captures generated on the device (rotation + counter-based dither of the seeded base set; synth.expand_capture
     # is the bit-identical host twin used for the parity check below)
-    first_unit = rank * D
+    if first_unit is None:
+        first_unit = rank * D
+    sizes = list(sizes) if sizes is not None else [D] * world
     gsmcal.synth_expand_dev(base_t.data_ptr(), nd, N, raw_t.data_ptr(), D, first_unit=first_unit, ctx=ctx)
     ctx.sync()
-    out_t = torch.zeros((D, 2), dtype=torch.float64, device=dev)
+    out_t = [torch.zeros((D, 2), dtype=torch.float64, device=dev) for _ in range(2)]
     host_out = torch.zeros((D, 2), dtype=torch.float64).pin_memory()
-    gathered = torch.zeros((world * D, 2), dtype=torch.float64, device=dev) if use_dist else None
+    host_gath = [torch.zeros((sum(sizes), 2), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
     cp = coef.ctypes.data_as(gsmcal._lib.c_double_p)
-
-    # single rank: the acceptance kernel stores (snr, num_hit) straight into pinned host memory (no copy queued)
-    dst_t = out_t if use_dist else host_out
+    nstep = [0]
 
     def step():
+        # single rank: the acceptance kernel stores (snr, num_hit) straight into pinned host memory (no copy queued).
+        # N > 1: the table stays in device memory, alternately in one of two buffers; the all-gather of step i (posted behind the
+        # kernels that fill buffer i & 1) overlaps the kernels of step i+1, the only wait is before a buffer is written again
+        b = nstep[0] & 1
+        nstep[0] += 1
+        if use_dist:
+            tg.wait(b)
+        dst_t = out_t[b] if use_dist else host_out
         ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
                                                      C.c_void_p(dst_t.data_ptr()), None, None, None), "scan")
         if use_dist:
-            dist.all_gather_into_tensor(gathered, out_t)
-            host_out.copy_(out_t, non_blocking=True)
+            tg.post(b, out_t[b])                                     # one RCCL all-gather of the (snr, num_hit) table
 
     def fence():
+        if use_dist:
+            for b in range(2):
+                if tg.work[b] is not None:
+                    host_gath[b].copy_(tg.rows(b), non_blocking=True)   # the GATHERED table to the host (every rank)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     elapsed = time_steps(torch, dev, step, steps, warmup, fence, prewarm_s=0.0 if use_dist else SUB_PREWARM_S)
+    gathered_ok = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    res = host_out.numpy().copy()
-    value = world * D * N * steps / elapsed / 1e6
+        last = (nstep[0] - 1) & 1
+        res = out_t[last].cpu().numpy()
+        # every rank checks every peer's block of the gathered table against that peer's own digest (independent gloo group)
+        from gsmcal import dist as gdist
+        chk = dist.new_group(backend="gloo")
+        g_all = host_gath[last].numpy()
+        gdist.check_gathered_table(g_all, res, sizes, rank, group=chk)
+        off = sum(sizes[:rank])
+        assert np.array_equal(g_all[off: off + D], res, equal_nan=True), "gathered scan table differs from this rank's rows"
+        gathered_ok = True
+    else:
+        res = host_out.numpy().copy()
+    value = sum(sizes) * N * steps / elapsed / 1e6
     out = {"ms_per_step": round(1e3 * elapsed / steps, 4), "value": round(value, 3),
            "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1),
            "path_frac_of_hbm": round(value * 1e6 * 2.25 / 1e9 / HBM_PEAK_GBS / world, 4),
-           "captures_with_hits": int(np.sum(res[:, 1] > 0))}
+           "captures_with_hits": int(np.sum(res[:, 1] > 0)),
+           "gathered_table_checked_against_every_rank": gathered_ok}
     if not args.no_kernel_events and rank == 0:
-        prof = event_pass(ctx, step, steps, torch, dev)
+        def launch_only():                                   # (no collective in here: only rank 0 runs this pass)
+            ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
+                                                         C.c_void_p((out_t[0] if use_dist else host_out).data_ptr()), None, None, None), "scan")
+        prof = event_pass(ctx, launch_only, steps, torch, dev)
         out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if D >= 1200:     # pipelined batch: stage k's detector and the tail of its front kernel run UNDER stage k+1's front kernel
             out["kernels_ms_per_step_untimed_pass"]["note"] = ("OVERLAPPED launches on the pipeline's internal streams: the per-kernel sums exceed the "
@@ -1045,20 +1090,37 @@ def bench_scan_main(args, rank, world, dev, use_dist):
     import torch.distributed as dist
 
     import gsmcal
+    from gsmcal import dist as gdist
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    ctx = gsmcal.Context(int(os.environ.get("LOCAL_RANK", "0")), stream=stream.cuda_stream)
-    r = bench_scan(args, torch, gsmcal, dev, ctx, args.streams, args.frames, args.distinct, args.steps, args.warmup,
-                   cpu=not args.no_cpu_baseline and world == 1, use_dist=use_dist, world=world, rank=rank)
-    D, N = args.streams, args.frames * 10000
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
+    # units = captures (dongle x ARFCN, multi_rtl_sdr_gsm_FCCH_scanner.m:60-65): --scaling weak = --streams captures per GPU,
+    # strong = --streams captures in total, block-contiguous shards (uneven shards are padded inside the gatherer)
+    if args.scaling == "strong":
+        sizes = gdist.shard_sizes(args.streams, world)
+        first_unit = gdist.shard_range(args.streams, world, rank)[0]
+    else:
+        sizes = [args.streams] * world
+        first_unit = rank * args.streams
+    D = sizes[rank]
+    if D < 1:
+        raise SystemExit("more ranks than captures")
+    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, 2) if use_dist else (None, "none", None, None)
+    r = bench_scan(args, torch, gsmcal, dev, ctx, D, args.frames, args.distinct, args.steps, args.warmup,
+                   cpu=not args.no_cpu_baseline and world == 1, use_dist=use_dist, world=world, rank=rank, sizes=sizes, tg=tg, first_unit=first_unit)
+    N = args.frames * 10000
     out = {"metric": "IQ Msamples/s through FCCH scanner path", "value": r["value"], "unit": "Msample/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
            "data": f"synthetic GSM uint8 IQ: {min(args.distinct, D)} seeded captures expanded on the device to {D} distinct ones "
                    "(3 of 4 base captures carry a BCCH carrier)",
-           "config": {"workload": f"scanner path multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,164-185: {D} captures/GPU x {N} "
-                                  f"IQ samples ({args.frames} frames), fir1(30), snr/num_hit on the host", "captures_per_gpu": D,
-                      "captures_with_hits": r["captures_with_hits"], "bytes_per_sample_algorithmic": 2.25},
+           "config": {"workload": f"scanner path multi_rtl_sdr_gsm_FCCH_scanner.m:60-65,132-135,164-185: {sum(sizes)} captures ({max(sizes)}/GPU) x {N} "
+                                  f"IQ samples ({args.frames} frames), fir1(30), snr/num_hit table on the host of every rank",
+                      "captures_per_gpu": max(sizes), "captures_total": sum(sizes),
+                      "captures_with_hits": r["captures_with_hits"], "bytes_per_sample_algorithmic": 2.25,
+                      "collective": COLLECTIVE_NAMES.get(gather_kind, gather_kind),
+                      "gathered_table_checked_against_every_rank": r["gathered_table_checked_against_every_rank"]},
            "roofline": {"bound": "hbm", "achieved": r["hbm_GBps_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": r["path_frac_of_hbm"], "traffic": None,
                         "what": "WHOLE PATH: Msample/s x 2.25 B/sample (2 B raw read + 16/64 B decimated write)",
@@ -1066,10 +1128,12 @@ def bench_scan_main(args, rank, world, dev, use_dist):
     for k in ("kernels_ms_per_step_untimed_pass", "parity_checked_captures", "cpu_baseline"):
         if k in r:
             out[k] = r[k]
+    if gather_fallback:
+        out["config"]["collective_fallback_from_native"] = gather_fallback
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
-        dist.destroy_process_group()
+        finish_dist(torch, dist, gdist, dev, ncomm, gather_fallback)
 
 
 def _oracle_warm(_):

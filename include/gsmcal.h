@@ -127,6 +127,13 @@ int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* ctx);
  * fused_launches: batch calls of this context that took the fused tail; gate_fallbacks: calls that would have but found
  * another context's fused tail unfinished (or ran inside the caller's own stream capture, where replays cannot be gated). */
 int gsmcal_fused_tail_stats(gsmcal_ctx* ctx, unsigned long long* fused_launches, unsigned long long* gate_fallbacks);
+/* The gate above is per process.  A fused tail stalled by ANOTHER process's fused tail on the same GPU gives up after
+ * GSMCAL_FUSED_POLL_S seconds (default 3) and reports it through a pinned host word; gsmcal_sync() and the host-buffer entry
+ * points then run the affected calls again with the four-launch tail (same inputs -- which the caller leaves untouched until it
+ * has synchronised -- same outputs) and return 0: the time-out costs seconds, not the call.  A caller that synchronises its
+ * stream without gsmcal_sync() sees GSMCAL_E_HIP in the status column of the affected rows instead.  Returns how often that
+ * happened on this context (test hook: GSMCAL_TEST_FUSED_STALL=<stage 1..4> makes one workgroup never publish). */
+long long gsmcal_fused_tail_reruns(gsmcal_ctx* ctx);
 /* device memory helpers so a host program needs no HIP headers */
 int gsmcal_dev_alloc(gsmcal_ctx* ctx, size_t bytes, void** dptr);
 int gsmcal_dev_free(gsmcal_ctx* ctx, void* dptr);

@@ -76,6 +76,10 @@ class Context:
     def pipeline_depth(self):
         return int(self.lib.gsmcal_ctx_get_pipeline_depth(self.h))
 
+    def fused_tail_reruns(self):
+        """how often gsmcal_sync / a host-buffer call re-ran calls with the four-launch tail after a fused tail timed out"""
+        return int(self.lib.gsmcal_fused_tail_reruns(self.h))
+
     def fused_tail_stats(self):
         """(batch calls that took the fused tail, calls the one-fused-tail-per-device gate sent to the four-launch tail)"""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

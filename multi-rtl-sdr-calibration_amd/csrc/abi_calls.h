@@ -105,6 +105,8 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (pe && atoi(pe) == 0) c->prescreen = false;
     const char* fg = getenv("GSMCAL_FRONT_GENERIC");
     if (fg && atoi(fg) != 0) c->front_generic = true;
+    if (const char* e2 = getenv("GSMCAL_FUSED_POLL_S")) { if (atof(e2) > 0.0) c->fused_poll_s = atof(e2); }
+    if (const char* e2 = getenv("GSMCAL_TEST_FUSED_STALL")) c->test_stall = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_PIPE_STAGES")) c->pipe_stages = atoi(e2) >= 3 ? 3 : (atoi(e2) <= 1 ? 1 : 2);
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
@@ -187,12 +189,41 @@ int gsmcal_fused_tail_stats(gsmcal_ctx* c, unsigned long long* fused_launches, u
     return 0;
 }
 
+// The context's streams have drained.  If a fused tail of the calls since the last check gave up waiting for a peer (the kernel's
+// poll limit: another process's fused tail held the slots its workgroups needed), run those calls again -- same inputs, which the
+// caller leaves untouched until it has synchronised -- with the four-launch tail, whose kernels wait for nobody.
+static int fused_recover(gsmcal_ctx* c) {
+    if (!c->fused_done || c->recovering) return 0;
+    volatile unsigned* flag = c->fused_done + gsmcal_ctx::FUSED_MAX_STREAMS;
+    if (*flag == 0u) { c->fused_calls.clear(); return 0; }
+    *flag = 0u;
+    std::vector<gsmcal_ctx::FusedCall> calls;
+    calls.swap(c->fused_calls);
+    const bool fp = c->fuse_post;
+    const int depth = c->pipe_depth;
+    c->fuse_post = false; c->pipe_depth = 1; c->recovering = true;
+    int rc = 0;
+    for (auto& k : calls) {
+        rc = gsmcal_calibrate_batch_dev(c, k.d_raw, k.d, k.n, k.coef.data(), k.ntaps, k.ts.data(), k.len_ts, k.cf.data(), k.d_table, k.d_pos_info, k.d_r_correct, k.d_r_len);
+        if (rc < 0) break;
+    }
+    hipError_t e = hipSuccess;
+    if (rc >= 0) e = hipStreamSynchronize(c->stream);
+    c->fuse_post = fp; c->pipe_depth = depth; c->recovering = false;
+    ++c->n_tail_reruns;
+    if (rc < 0) return rc;
+    if (e != hipSuccess) { c->err = std::string("hipStreamSynchronize (fused tail re-run): ") + hipGetErrorString(e); return GSMCAL_E_HIP; }
+    return 0;
+}
+
 int gsmcal_sync(gsmcal_ctx* c) {
     if (!c) return GSMCAL_E_ARG;
     RET_IF(pipe_drain(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return fused_recover(c);
 }
+
+long long gsmcal_fused_tail_reruns(gsmcal_ctx* c) { return c ? (long long)c->n_tail_reruns : (long long)GSMCAL_E_ARG; }
 
 // ---- pipelined batch calls ----------------------------------------------------------------------------------------
 int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* c, int depth) {
@@ -735,6 +766,14 @@ int gsmcal_fcch_scan_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     return 0;
 }
 
+// (a call that took the fused tail: what fused_recover needs to run it again; the inputs are the context's cached copies)
+static void record_fused_call(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, int ntaps, int len_ts, double* d_table, double* d_pos_info,
+                              double* d_r_correct, long* d_r_len) {
+    if (c->recovering) return;
+    if (c->fused_calls.size() >= 16) c->fused_calls.erase(c->fused_calls.begin());      // (a caller that never synchronises through the library)
+    c->fused_calls.push_back({d_raw, d, n, ntaps, len_ts, c->h_coef, c->h_ts, c->h_cf, d_table, d_pos_info, d_r_correct, d_r_len});
+}
+
 int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
                                const double* sch_ts, int len_ts, const double* carrier_freq, double* d_table,
                                double* d_pos_info, double* d_r_correct, long* d_r_len) {
@@ -820,6 +859,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         c->pipe_last_slot = slot;
         c->pipe_last_stages = nst == 1 ? 1 : (out_stream == c->pipe_stream[2] ? 3 : 2);
         ++c->pipe_calls;
+        if (rc >= 0 && co.fused) record_fused_call(c, d_raw, d, n, ntaps, len_ts, d_table, d_pos_info, d_r_correct, d_r_len);
         c->detail_lane = &L;
         c->cur = &c->lanes[0];
         c->last_S = d;
@@ -885,7 +925,9 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(join_lanes(c, nl));
     return 0;
     };
+    const unsigned long long fused_before = c->n_fused_launches;
     RET_IF(run_maybe_graph(c, pick_slot(c, c->g_calib, key), key, enqueue, plan_lanes(c, d) > 1));
+    if (c->n_fused_launches != fused_before) record_fused_call(c, d_raw, d, n, ntaps, len_ts, d_table, d_pos_info, d_r_correct, d_r_len);
     plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
     c->cur = &c->lanes[0];
     c->last_S = d;
@@ -907,6 +949,10 @@ int gsmcal_calibrate_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
                                       (double*)c->table.p, (double*)c->posinfo.p,
                                       r_correct ? (double*)c->arr_out.p : nullptr, (long*)c->rlen.p));
     RET_IF(pipe_join(c));                      // (a pipelined context: the copies below wait for this call like for any other)
+    if (!c->fused_calls.empty()) {             // (the fused tail ran: had it timed out, the call runs again as four launches before anything is copied)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        RET_IF(fused_recover(c));
+    }
     HIPCHK(c, hipMemcpyAsync(table, c->table.p, (size_t)d * GSMCAL_TABLE_COLS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (pos_info)
         HIPCHK(c, hipMemcpyAsync(pos_info, c->posinfo.p, (size_t)d * 2 * MAXROWS * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -86,6 +86,19 @@ struct gsmcal_ctx {
     int fused_hi = 0;               // streams [0, fused_hi) may have a fused tail in flight
     unsigned long long n_fused_launches = 0, n_gate_fallbacks = 0;   // gsmcal_fused_tail_stats
     int capture_fused_streams = 0;  // streams of the fused tail enqueued during the stream capture in progress
+    // A fused tail whose workgroups gave up waiting for a peer (another PROCESS's fused tail holding the slots: outside the gate) tells
+    // the host through a pinned word; gsmcal_sync / the host-buffer entry points then run the recorded calls again with the
+    // four-launch tail (fused_recover in abi_calls.h).
+    struct FusedCall {
+        const uint8_t* d_raw; int d; long n; int ntaps, len_ts;
+        std::vector<double> coef, ts, cf;
+        double* d_table; double* d_pos_info; double* d_r_correct; long* d_r_len;
+    };
+    std::vector<FusedCall> fused_calls;    // calls that took the fused tail since the last synchronisation that found no time-out (at most 16)
+    double fused_poll_s = 3.0;             // GSMCAL_FUSED_POLL_S: how long a workgroup waits for its stream's peers
+    int test_stall = 0;                    // GSMCAL_TEST_FUSED_STALL=<1..4> (test hook): one workgroup never publishes that stage's result
+    unsigned long long n_tail_reruns = 0;  // gsmcal_fused_tail_reruns
+    bool recovering = false;
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
@@ -379,7 +392,7 @@ struct FusedGate { std::mutex mu; std::vector<gsmcal_ctx*> ctxs; };
 inline FusedGate& fused_gate() { static FusedGate g; return g; }
 
 void fused_gate_register(gsmcal_ctx* c) {
-    const size_t bytes = (size_t)gsmcal_ctx::FUSED_MAX_STREAMS * sizeof(unsigned);
+    const size_t bytes = ((size_t)gsmcal_ctx::FUSED_MAX_STREAMS + 16) * sizeof(unsigned);     // (+ the time-out word behind the per-stream words)
     if (hipHostMalloc((void**)&c->fused_done, bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->fused_done = nullptr; }
     if (c->fused_done) memset(c->fused_done, 0, bytes);
     c->fused_expected.assign(gsmcal_ctx::FUSED_MAX_STREAMS, 0u);
@@ -427,9 +440,25 @@ bool fused_gate_pass(gsmcal_ctx* c, int streams) {
     return true;
 }
 
+// (gate mutex NOT held) a fused tail that was counted by fused_gate_pass() never reached the queue (failed launch / graph launch):
+// take it out of the count again, or this context would read as busy for good and every other context of the device would lose
+// the fused tail for the rest of the process
+void fused_gate_rollback(gsmcal_ctx* c, int streams) {
+    std::lock_guard<std::mutex> lk(fused_gate().mu);
+    for (int s = 0; s < streams && s < gsmcal_ctx::FUSED_MAX_STREAMS; ++s)
+        if (c->fused_expected[s] > 0) --c->fused_expected[s];
+    if (c->n_fused_launches > 0) --c->n_fused_launches;
+}
+
 // May context c enqueue a fused tail over `streams` streams now?  false: take the four-launch tail.
 bool fused_gate_enter(gsmcal_ctx* c, int streams) {
-    if (c->capturing) { c->capture_fused_streams = streams; return c->fused_done != nullptr; }   // our own capture: run_maybe_graph passes the gate at every replay
+    if (c->capturing) {
+        // our own capture: run_maybe_graph passes the gate at every replay, counting ONE fused tail over capture_fused_streams
+        // streams per replay -- a second fused tail inside the same captured plan takes the four-launch form
+        if (c->capture_fused_streams > 0 || !c->fused_done) return false;
+        c->capture_fused_streams = streams;
+        return true;
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (c->stream && (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
         (void)hipGetLastError();                          // the CALLER is capturing: the library will not see the replays -- never fuse
@@ -500,6 +529,9 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
     if (!fg.raw) RET_IF(launch_gather(c, S, src, lvl, g.fine_wlen, false, H, win, sstride, wstride));
     // from here on the lane's window buffer holds level 0 of every fine window (nothing later in a batch call writes it)
     c->cur->win_l0_len = (src.kind == SRC_RAW && lvl == 0) ? g.fine_wlen : 0;
+#if defined(GSMCAL_AB_NO_REUSE_L0) || defined(GSMCAL_AB_LAZY_WIN)
+    c->cur->win_l0_len = 0;      // A/B builds of tools/ab_traffic.sh only: every per-burst gather filters its raw bytes again (no read of the window buffer)
+#endif
     c->cur->win_l0_H = H;
     StepArgs sa_fine = sa;
     if (c->prescreen) {
@@ -603,10 +635,20 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.rec = (const ChunkRec*)c->cur->chunkrec.p; pa.cert = certp; pa.peaks = peaks; pa.n_open = n_open;
                 pa.with_totals = chain->table ? 1 : 0;
                 pa.done = c->fused_done;
+                pa.timed_out = c->fused_done ? c->fused_done + gsmcal_ctx::FUSED_MAX_STREAMS : nullptr;
+                pa.poll_ticks = (unsigned long long)(c->fused_poll_s * 1e8);
+                pa.test_stall = c->recovering ? 0 : c->test_stall;
                 if (c->tail_wait) HIPCHK(c, hipStreamWaitEvent(c->cur->stream, c->tail_wait, 0));
                 if (ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
                 else LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
-                CHECK_LAUNCH(c);
+                {
+                    const hipError_t le = hipGetLastError();
+                    if (le != hipSuccess) {
+                        if (!c->capturing) fused_gate_rollback(c, S);     // (counted by fused_gate_enter above, never enqueued)
+                        c->err = std::string("k_post_chain_r launch: ") + hipGetErrorString(le);
+                        return GSMCAL_E_HIP;
+                    }
+                }
                 if (c->tail_record) HIPCHK(c, hipEventRecord(c->tail_record, c->cur->stream));
                 return 0;
             }
@@ -1069,7 +1111,12 @@ int run_maybe_graph(gsmcal_ctx* c, gsmcal_ctx::GraphSlot& slot, const std::vecto
             }
             if (!ok) return enqueue();
         }
-        HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
+        const hipError_t ge = hipGraphLaunch(slot.exec, c->stream);
+        if (ge != hipSuccess) {
+            if (slot.fused_streams > 0) fused_gate_rollback(c, slot.fused_streams);     // (counted above, never enqueued)
+            c->err = std::string("hipGraphLaunch: ") + hipGetErrorString(ge);
+            return GSMCAL_E_HIP;
+        }
         return 0;
     };
     if (same && slot.exec) return replay();

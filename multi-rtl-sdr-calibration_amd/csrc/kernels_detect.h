@@ -1873,10 +1873,17 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
                 } else if (ntp == 47) fir4_lds<47>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
                 else fir4_lds<0>(xq, c_s, i0, ntp, &y0, &y1, &y2, &y3);
                 const int o = o0 + i0;
+#ifdef GSMCAL_AB_LAZY_WIN      /* A/B build of tools/ab_traffic.sh only: the window goes out at the end, and only if the certificate left chunks open */
+                xs[FC_XP(o)] = y0;
+                if (i0 + 1 < cnt) xs[FC_XP(o + 1)] = y1;
+                if (i0 + 2 < cnt) xs[FC_XP(o + 2)] = y2;
+                if (i0 + 3 < cnt) xs[FC_XP(o + 3)] = y3;
+#else
                 xs[FC_XP(o)] = y0; wout[o] = y0;
                 if (i0 + 1 < cnt) { xs[FC_XP(o + 1)] = y1; wout[o + 1] = y1; }
                 if (i0 + 2 < cnt) { xs[FC_XP(o + 2)] = y2; wout[o + 2] = y2; }
                 if (i0 + 3 < cnt) { xs[FC_XP(o + 3)] = y3; wout[o + 3] = y3; }
+#endif
             }
             __syncthreads();
             DEV_STAMP(KID_CERT, blockIdx.y * gridDim.x + blockIdx.x, 9 + (o0 > 0) + (o0 > per));
@@ -2162,6 +2169,12 @@ __global__ void __launch_bounds__(512) k_fine_cert(const StreamState* __restrict
         }
     }
     __syncthreads();
+#ifdef GSMCAL_AB_LAZY_WIN
+    if (fg.raw && OV > 0 && NTAPS == 47 && fg.sym47 != 0 && (sh_a != 0 || sh_b < nstep)) {      // (block-uniform) chunks stay open: k_fine_chunk / the exact pass read the window
+        cplx* wout = fg.win_out + (size_t)s * win_stream_stride + (size_t)w * win_stride;
+        for (int i = tid; i < wlen; i += nthr) wout[i] = xs[FC_XP(i)];
+    }
+#endif
     if (tid == 0) {
         FineCert o;
         o.p = best; o.t = bt; o.k = bk; o.a = sh_a; o.b = sh_b;

@@ -1063,6 +1063,9 @@ struct PostChainArgs {
     StepArgs sa;                       // one set of step arguments serves every decision step (NB = 1)
     unsigned* done;                    // pinned host words of the context, one per stream: the launch count of the stream's last finished
                                        // fused tail (gsmcal_ctx::fused_done; nullptr: not reported)
+    unsigned* timed_out;               // pinned host word: set when a workgroup gave up waiting for a peer (the host then re-runs the tail as four launches)
+    unsigned long long poll_ticks;     // how long a workgroup waits for its stream's peers at an exchange, in 100 MHz wall-clock ticks
+    int test_stall;                    // test hook: > 0: workgroup (1, 0) never publishes its stage-(test_stall - 1) granules
     int lvl_fine, lvl_sch, lvl_post;   // input levels of the three reference functions
     int nfft, ov, len_ts, sch_nshift, fine_nshift, H;
     const cplx* tw_g; const cplx* ts;
@@ -1109,23 +1112,36 @@ __device__ __forceinline__ unsigned long long pcr_word(double v) {
 
 // publish r0, r1 as this workgroup's granules of `stage`, then collect the stream's 2*H granules into all[] (LDS)
 __device__ __forceinline__ void pcr_exchange(unsigned long long* __restrict__ slots, int H, int w, unsigned long long r0,
-                                             unsigned long long r1, unsigned long long* all, int* sh_status, bool collect) {
+                                             unsigned long long r1, unsigned long long* all, StreamState* sh, bool collect,
+                                             unsigned long long poll_ticks, unsigned* __restrict__ timed_out, bool publish = true) {
     const int tid = threadIdx.x;
-    if (tid < 2) __hip_atomic_store(slots + 2 * w + tid, tid ? r1 : r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2 && publish) __hip_atomic_store(slots + 2 * w + tid, tid ? r1 : r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!collect) return;
     if (tid < 64) {
         const bool mine = tid < 2 * H;
         unsigned long long v = PCR_EMPTY;
-        long spins = 0;
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
         bool bad = false;
         while (true) {
             if (mine && v == PCR_EMPTY) v = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__ballot(mine && v == PCR_EMPTY)) break;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > 40000000L) { bad = true; break; }      // a peer never came (not observed): fail, do not hang the queue
+            // a peer that does not come within poll_ticks (seconds; the constant-rate 100 MHz counter, looked at every 256 polls):
+            // give up -- the rows of this stream report GSMCAL_E_HIP and the host, told through its pinned word, re-runs the tail
+            // of the call as four launches (host_plan.h: fused_recover).  Never a hang, and no longer a lost call.
+            if ((++spins & 255u) == 0u) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > poll_ticks) { bad = true; break; }
+            }
         }
         if (mine) all[tid] = v;
-        if (bad && tid == 0 && *sh_status >= 0) *sh_status = GSMCAL_E_HIP;
+        if (bad && tid == 0) {
+            if (sh->status >= 0) sh->status = GSMCAL_E_HIP;
+            sh->n_win = 0;                                           // (nothing downstream computes on the words that never came)
+            if (timed_out) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __syncthreads();
 }
@@ -1179,13 +1195,18 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     }
     if (tid == 0) { pk.p = -1.0; pk.tie = 0; pk.k = 0; res[0] = 0.0; res[1] = 0.0; }
     __syncthreads();
+    // A peer of this stream that never publishes (pcr_exchange gives up: status < 0 and n_win = 0 in every workgroup that waited for
+    // it) loses the stream for this launch: with no windows left every later stage body returns at once and every decision step is
+    // a no-op (they all start from n_win / a non-negative status), the remaining exchanges are passed without waiting (everybody
+    // publishes at once), and workgroup 0 still writes the row (status GSMCAL_E_HIP), the launch count and the host's word.  The
+    // host then runs the call again as four launches (abi_calls.h: fused_recover).
     // ---- stage 0: the fine search's exact last word per window -> FINE_DECIDE (FCCH_fine_correction.m:52-137) ----
     fine_verify_body<PC_THREADS, 6>(shv, a.win, a.win_stream_stride, a.win_stride, a.fine_nshift, a.nfft, a.tw_g, a.rec, a.peaks, a.H,
                                  a.cert, a.n_open, smem, &pk);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 1);
     pcr_exchange(mine_x, H, w, pcr_word(pk.p), (unsigned long long)(unsigned)pk.tie | ((unsigned long long)(unsigned)pk.k << 32), all,
-                 &sh->status, true);
+                 sh, true, a.poll_ticks, a.timed_out, !(a.test_stall == 1 && w == 1 && s == 0));
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);                              // the stream waits for this wave: it issues ahead of everything else on its SIMD (62.2 -> 61.2 us)
         if (lane < sh->n_win && lane < MAXH && lane < H) {
@@ -1203,7 +1224,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     burst_tone_body<1>(shv, a.ga1, a.nfft, a.tw_g, a.ov, 1, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 4);
-    pcr_exchange(mine_x + XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    pcr_exchange(mine_x + XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, sh, true, a.poll_ticks, a.timed_out, !(a.test_stall == 2 && w == 1 && s == 0));
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);
         if (lane < H && lane < MAXH) {
@@ -1223,7 +1244,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     window_sch_body<(OV > 0 ? 2 : 1), (OV == 8 && LT == 512)>(shv, a.ga_sch, a.ts, a.len_ts, a.sch_nshift, smem, res);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 7);
-    pcr_exchange(mine_x + 2 * XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, &sh->status, true);
+    pcr_exchange(mine_x + 2 * XST, H, w, pcr_word(res[0]), pcr_word(res[1]), all, sh, true, a.poll_ticks, a.timed_out, !(a.test_stall == 3 && w == 1 && s == 0));
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);
         const bool act = lane < H && lane < MAXH && lane < n_sch_win;
@@ -1242,7 +1263,7 @@ k_post_chain_r(StreamState* __restrict__ sts, PostChainArgs a_in, unsigned long 
     burst_tone_body<0>(shv, a.ga0, a.nfft, a.tw_g, a.ov, 0, smem, res, true);
     __syncthreads();
     DEV_STAMP(KID_GATHER, blockIdx.y * gridDim.x + blockIdx.x, 10);
-    pcr_exchange(mine_x + 3 * XST, H, w, pcr_word(res[0]), 0ull, all, &sh->status, w == 0);
+    pcr_exchange(mine_x + 3 * XST, H, w, pcr_word(res[0]), 0ull, all, sh, w == 0, a.poll_ticks, a.timed_out, !(a.test_stall == 4 && w == 1 && s == 0));
     if (w != 0) return;                                             // workgroup 0 finishes the stream
     if (tid < 64) {
         __builtin_amdgcn_s_setprio(3);

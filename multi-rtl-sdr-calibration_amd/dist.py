@@ -157,6 +157,10 @@ class NativeTableGatherer:
             raise TypeError("gsmcal_allgather_table moves doubles (ncclDouble): the table must be float64")
         self.stream = stream if stream is not None else (torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None)
         ctx_stream = getattr(ctx, "stream_handle", None)
+        # a context that owns its (non-blocking) stream: no torch stream wraps it, so stream order cannot put torch's pad copies /
+        # re-assembly and the library's collective in sequence -- this class then synchronises on the host around them
+        # (slower, correct); contexts created on a torch stream (bench.py) pay nothing
+        self._foreign = self.stream is not None and ctx_stream is None
         if self.stream is not None and ctx_stream is not None and int(self.stream.cuda_stream) != int(ctx_stream):
             raise ValueError("NativeTableGatherer: the torch stream is not the context's stream -- pad copies would race the collective")
         with self._on_stream():
@@ -179,8 +183,12 @@ class NativeTableGatherer:
         self.wait(b)
         src = local
         if local.shape[0] != self.mx or not local.is_contiguous():     # uneven shards: pad to the largest (NaN rows are dropped by rows())
+            if self._foreign:
+                self.ctx.sync()                                       # (`local` was written on the context's stream)
             with self._on_stream():
                 self.send[b][: local.shape[0]].copy_(local)
+                if self._foreign:
+                    self.stream.synchronize()                         # (... and the collective below must see the copy)
             src = self.send[b]
         if self.mode == "async":
             self.ctx.check(self.ctx.lib.gsmcal_allgather_table_async(self.ctx.h, self.comm.h, C.c_void_p(src.data_ptr()), self.mx, self.cols,
@@ -199,6 +207,8 @@ class NativeTableGatherer:
         import torch
         if self.work[b] is not None and self.mode == "async":
             self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
+        if self._foreign:
+            self.ctx.sync()                                           # (readers of the returned tensor run on torch's stream)
         if all(s == self.mx for s in self.sizes):
             return self.recv[b]
         with self._on_stream():
@@ -209,8 +219,11 @@ class NativeTableGatherer:
         return self.recv[b][off: off + self.sizes[self.rank]]
 
     def reset(self, mode=None):
-        """forget the posted buffers (between two timing trials) and optionally switch the placement of the collective"""
+        """forget the posted buffers (between two timing trials) and optionally switch the placement of the collective; a
+        collective still in flight on the side stream is waited for first (the context's stream is ordered behind it)"""
         for b in range(2):
+            if self.work[b] is not None and self.mode == "async":
+                self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
             self.work[b] = None
         if mode is not None:
             self.mode = mode
@@ -301,12 +314,40 @@ def verify_gatherer(tg, cols, device, sync, timeout_s=60.0):
     local = (1000.0 * tg.rank + torch.arange(n, dtype=torch.float64).reshape(n, 1) + torch.arange(cols, dtype=torch.float64).reshape(1, cols) / 16.0).to(device)
     for b in range(2):
         tg.post(b, local)
-    got = [tg.rows(b).clone() for b in range(2)]
+    import contextlib
+    on_stream = tg._on_stream() if hasattr(tg, "_on_stream") else contextlib.nullcontext()
+    with on_stream:                                           # (the clones run on the stream the gatherer's own torch work runs on)
+        got = [tg.rows(b).clone() for b in range(2)]
     call_with_timeout(sync, timeout_s)
     for b in range(2):
         if not torch.equal(got[b].cpu(), want):
             raise RuntimeError(f"trial all-gather returned a wrong table on rank {tg.rank} (buffer pair {b})")
         tg.work[b] = None
+
+
+def check_gathered_table(gathered, local, sizes, rank, group=None):
+    """The collective's result against what every rank says it sent: SHA-256 digests of the ranks' local rows travel through
+    `group` (an independent group -- gloo over TCP in bench.py -- never the communicator under test), and this rank compares
+    EVERY peer's block of its gathered table with that peer's digest, not only its own rows.  gathered: host array
+    [sum(sizes), cols] in global unit order; local: this rank's rows [sizes[rank], cols].  Serves both tables of the ABI: the
+    calibration table (10 columns, gsm_sync_demod.m:123-124) and the scanner's (snr, num_hit) table
+    (multi_rtl_sdr_gsm_FCCH_scanner.m:163-186).  Raises AssertionError naming the rank whose rows differ; returns True."""
+    import hashlib
+    import torch.distributed as dist
+    gathered = np.ascontiguousarray(gathered)
+    local = np.ascontiguousarray(local)
+    world = len(sizes)
+    assert gathered.shape[0] == sum(sizes), f"rank {rank}: gathered table has {gathered.shape[0]} rows, the shards add up to {sum(sizes)}"
+    assert local.shape[0] == sizes[rank] and local.shape[1:] == gathered.shape[1:]
+    mine = hashlib.sha256(local.tobytes()).hexdigest()
+    digests = [None] * world
+    dist.all_gather_object(digests, mine, group=group)
+    off = 0
+    for r in range(world):
+        blk = np.ascontiguousarray(gathered[off: off + sizes[r]])
+        assert hashlib.sha256(blk.tobytes()).hexdigest() == digests[r], f"rank {rank}: rank {r}'s rows in the gathered table differ from what it sent"
+        off += sizes[r]
+    return True
 
 
 def broadcast_unique_id(ctx, device, group=None):

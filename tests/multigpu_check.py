@@ -13,7 +13,9 @@ layout under gloo: tests/test_dist_cpu.py).  One process per GPU; runs BOTH coll
      nonce, with a stale id file of another launch planted at the path first, and (c) by bench.py's current N > 1
      exchange: NativeTableGatherer (in line and on the side stream) on a communicator bootstrapped through the process group,
      and (d) through the decisions bench.py takes before its timed loop (gsmcal.dist.choose_gatherer with a checked trial exchange,
-     autotune_placement): every rank must end on the native gatherer and the same placement;
+     autotune_placement): every rank must end on the native gatherer and the same placement; (e) the SCANNER workload's
+     (snr, num_hit) table of 13 captures (uneven split) through the native collective with two columns, in line and on the side
+     stream, with the digest check of every peer's block; (f) pipelined calibration calls with the collective behind each;
   4. every rank compares all gathered tables, row by row and bit for bit, with the table it computes for ALL units on its
      own GPU (unit independence makes that the expected result), and rank 0 checks unit 0 against the CPU oracle.
 
@@ -200,10 +202,71 @@ def main():
             res = gsmcal.calibrate_batch(raw[:1], coef, ts, fc, ctx=ctx)
             parity.compare_stream(oracle.calibrate_stream(raw[0], coef, ts, fc), res["table"][0],
                                   gsmcal.last_batch_details(1, ctx=ctx), 0, res["pos_info"][0])
+    # (e) the scanner workload's exchange (BASELINE config 5, multi_rtl_sdr_gsm_FCCH_scanner.m:60-65,163-186): 13 captures (the
+    # uneven split) through gsmcal_fcch_scan_batch_dev on every rank's shard, the (snr, num_hit) table gathered by the native
+    # collective with TWO columns -- in line and on the side stream, double-buffered as bench.py --workload scan posts it -- every
+    # rank comparing the gathered table with the table it computes for ALL captures, and every peer's block with that peer's
+    # digest (gsmcal.dist.check_gathered_table through an independent gloo group)
+    coef30 = np.ascontiguousarray(synth.fir1(30, 200e3 / synth.FS))
+    ncap, nscan = 13, 64 * synth.FRAME_OV
+    caps = np.stack([synth.make_stream(dongle=4100, arfcn=u, num_frames=64, bcch=(u % 4 != 3))[0] for u in range(ncap)])
+    full_sc = gsmcal.fcch_scan_batch(caps, coef30, ctx=ctx)
+    full_tab = np.stack([np.asarray(full_sc["snr"], dtype=np.float64), np.asarray(full_sc["num_hit"], dtype=np.float64)], axis=1)
+    lo, hi = gd.shard_range(ncap, world, rank)
+    sizes = gd.shard_sizes(ncap, world)
+    chk = dist.new_group(backend="gloo")
+    comm3 = gd.native_comm_from_process_group(ctx, dev)
+    try:
+        raw_sc = torch.from_numpy(np.ascontiguousarray(caps[lo:hi])).to(dev) if hi > lo else torch.zeros((0, 2 * nscan), dtype=torch.uint8, device=dev)
+        outs = [torch.zeros((hi - lo, 2), dtype=torch.float64, device=dev) for _ in range(2)]
+        for mode in ("inline", "async"):
+            stg = gd.NativeTableGatherer(ctx, comm3, sizes, 2, dev, mode=mode, stream=stream)
+            for step in range(4):
+                b = step & 1
+                stg.wait(b)
+                if hi > lo:
+                    gsmcal.fcch_scan_batch_dev(raw_sc.data_ptr(), hi - lo, nscan, coef30, outs[b].data_ptr(), ctx=ctx)
+                stg.post(b, outs[b])
+            for b in (0, 1):
+                rows = stg.rows(b)
+                torch.cuda.synchronize(dev)
+                if mode == "async":
+                    ctx.check(ctx.lib.gsmcal_allgather_sync(ctx.h, b), "gsmcal_allgather_sync")
+                got = rows.cpu().numpy()
+                assert np.array_equal(got, full_tab, equal_nan=True), f"scan table, native gatherer {mode}, buffer {b}"
+                gd.check_gathered_table(got, outs[b].cpu().numpy(), sizes, rank, group=chk)
+    finally:
+        torch.cuda.synchronize(dev)
+        comm3.close()
+    # (f) pipelined calibration calls (gsmcal_ctx_set_pipeline_depth(2)) with the native collective right behind each call: the
+    # all-gather rides on the stream of the call's last stage; after gsmcal_sync every gathered table is the full table
+    num_units = 16
+    raw = np.stack([synth.make_stream(dongle=4000 + u, num_frames=args.frames)[0] for u in range(num_units)])
+    full = gsmcal.calibrate_batch(raw, coef, ts, fc, ctx=ctx)["table"]
+    lo, hi = gd.shard_range(num_units, world, rank)
+    sizes = gd.shard_sizes(num_units, world)
+    if all(sz == sizes[0] for sz in sizes):          # (even shards only: the pad copies of uneven ones are torch's, on the context's stream)
+        comm4 = gd.native_comm_from_process_group(ctx, dev)
+        try:
+            raw_t = torch.from_numpy(np.ascontiguousarray(raw[lo:hi])).to(dev)
+            tabs = [torch.zeros((hi - lo, gsmcal.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(4)]
+            ptg = gd.NativeTableGatherer(ctx, comm4, sizes, gsmcal.TABLE_COLS, dev, mode="inline", stream=stream)
+            ctx.set_pipeline_depth(2)
+            for step in range(4):
+                gsmcal.calibrate_batch_dev(raw_t.data_ptr(), hi - lo, raw.shape[1] // 2, coef, ts, fc, tabs[step].data_ptr(), ctx=ctx)
+                ptg.post(step & 1, tabs[step])
+            ctx.sync()
+            ctx.set_pipeline_depth(1)
+            for b in (0, 1):
+                assert np.array_equal(ptg.rows(b).cpu().numpy(), full, equal_nan=True), f"pipelined calls + in-line collective, buffer {b}"
+        finally:
+            ctx.set_pipeline_depth(1)
+            torch.cuda.synchronize(dev)
+            comm4.close()
     comm.close()
     assert not os.path.exists(id_path), "rank 0 should have removed the id file once the communicator was up"
     dist.barrier()
-    print(f"multigpu_check OK: rank {rank}/{world}, units 7 (uneven) and 16, torch + native all-gather, tables bit-identical")
+    print(f"multigpu_check OK: rank {rank}/{world}, units 7 (uneven) and 16, torch + native all-gather, scan table of 13 captures, pipelined calls, tables bit-identical")
     dist.destroy_process_group()
 
 

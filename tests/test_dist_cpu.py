@@ -98,6 +98,75 @@ def test_bench_exchange_step_under_gloo(num_units):
             assert np.array_equal(res[r][step], want), f"rank {r} step {step}"
 
 
+def _scan_row(u):
+    """(snr, num_hit) of capture u as the scanner's acceptance rule leaves it: -1 / 0 for a capture without an FCCH"""
+    return np.array([-1.0, 0.0]) if u % 4 == 3 else np.array([17.25 + 0.125 * u, 3.0 + (u % 3)])
+
+
+def _scan_exchange_worker(rank, world, num_caps, corrupt, port, q):
+    sys.path.insert(0, ROOT)
+    from gsmcal import dist as gd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = gd.shard_sizes(num_caps, world)
+    lo, hi = gd.shard_range(num_caps, world, rank)
+    tg = gd.TableGatherer(sizes, 2, torch.device("cpu"))
+    chk = dist.new_group(backend="gloo")
+    outs = [torch.zeros((hi - lo, 2), dtype=torch.float64) for _ in range(2)]
+    host_gath = [None, None]
+    nstep = 0
+    for _ in range(5):                                       # bench.py --workload scan: the step of bench_scan()
+        b = nstep & 1
+        nstep += 1
+        tg.wait(b)
+        outs[b].copy_(torch.tensor(np.stack([_scan_row(u) for u in range(lo, hi)]).reshape(hi - lo, 2)) + 1000.0 * nstep)   # the "kernel" fills buffer b
+        tg.post(b, outs[b])
+    for b in range(2):                                       # its fence: the GATHERED table to the host
+        if tg.work[b] is not None:
+            host_gath[b] = tg.rows(b).clone().numpy()
+    last = (nstep - 1) & 1
+    g_all = host_gath[last]
+    if corrupt and rank == 1:
+        g_all = g_all.copy()
+        g_all[0, 0] += 1e-9                                  # one bit of rank 0's block arrives wrong on rank 1
+    res = {"rank": rank, "rows": g_all.copy()}
+    try:
+        gd.check_gathered_table(g_all, outs[last].numpy(), sizes, rank, group=chk)
+        res["ok"] = True
+    except AssertionError as e:
+        res["ok"], res["why"] = False, str(e)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_caps,corrupt", [(13, False), (400, False), (13, True)])
+def test_scan_exchange_step_under_gloo(num_caps, corrupt):
+    """BASELINE config 5's exchange (multi_rtl_sdr_gsm_FCCH_scanner.m:60-65,163-186): bench.py --workload scan's
+    step -- the (snr, num_hit) table of this rank's captures into one of two buffers, ONE all-gather of it per step, the gathered
+    table to the host at the fence -- on two gloo ranks with an UNEVEN capture split (13 -> 6 + 7), followed by the check every
+    rank makes of every peer's block against that peer's digest (gsmcal.dist.check_gathered_table).  A single wrong bit in a
+    peer's block on one rank must be caught there and only there."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000) + num_caps % 89 + (7 if corrupt else 0)
+    procs = [ctx.Process(target=_scan_exchange_worker, args=(r, world, num_caps, corrupt, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_scan_row(u) for u in range(num_caps)]) + 1000.0 * 5
+    assert res[0]["ok"] and np.array_equal(res[0]["rows"], want)
+    if corrupt:
+        assert not res[1]["ok"] and "rank 0's rows" in res[1]["why"]
+    else:
+        assert res[1]["ok"] and np.array_equal(res[1]["rows"], want)
+
+
 class _FakeNative:
     """stands in for NativeTableGatherer in the decision-logic tests: same post / rows / reset surface, moves the rows with
     a process group of its OWN (as the native communicator is a communicator of its own: a rank stuck in it does not

@@ -205,6 +205,36 @@ def test_bench_distributed_step_on_one_rank_and_its_fall_back(fail_native):
         assert "native RCCL" in cfg["collective"] and "collective_fallback_from_native" not in cfg
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_native", [False, True])
+def test_bench_scan_workload_distributed_step_on_one_rank(fail_native):
+    """BASELINE config 5's exchange as `bench.py --workload scan` runs it with N > 1, on one rank
+    (GSMCAL_FORCE_DIST=1): process group, native communicator chosen by gsmcal.dist.choose_gatherer with its checked trial
+    exchange, ONE all-gather of the (snr, num_hit) table per step (two columns), the gathered table on the host, every peer's
+    block against its digest -- and the fall-back to torch's collective when the native set-up fails."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSMCAL_FORCE_DIST"] = "1"
+    if fail_native:
+        env["GSMCAL_BENCH_FAIL_NATIVE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "scan", "--steps", "3", "--warmup", "1", "--streams", "50",
+           "--frames", "64", "--distinct", "8", "--no-cpu-baseline", "--no-kernel-events"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert p.returncode == 0 and line, p.stderr[-2000:]
+    r = json.loads(line[-1])
+    cfg = r["config"]
+    assert cfg["gathered_table_checked_against_every_rank"] is True
+    assert cfg["captures_total"] == 50 and cfg["captures_with_hits"] > 0 and r["parity_checked_captures"] >= 3
+    if fail_native:
+        assert cfg["collective"].endswith("torch.distributed over RCCL")
+        assert "GSMCAL_BENCH_FAIL_NATIVE" in cfg["collective_fallback_from_native"]
+    else:
+        assert "native RCCL" in cfg["collective"] and "collective_fallback_from_native" not in cfg
+
+
 @pytest.mark.parametrize("n_samples", [250000, 250003])
 def test_scanner_pipeline_choices_change_no_bit(g_mod, ctx, monkeypatch, n_samples):
     """A scanner batch big enough for the pipeline (2 100 captures: 8 stages) through every way the library can schedule it --

@@ -480,6 +480,50 @@ def test_fine_search_modes_and_lanes_agree(g, setup, monkeypatch, env):
     assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
 
 
+@pytest.mark.parametrize("stage", [1, 2, 3, 4])
+def test_fused_tail_time_out_is_recovered_with_the_four_launch_tail(g, setup, monkeypatch, stage):
+    """a fused tail whose workgroups give up waiting for a peer (in production: another PROCESS's fused tail holding
+    the slots; here the test hook GSMCAL_TEST_FUSED_STALL -- workgroup (1, 0) never publishes that stage's result -- with the wait
+    cut to 50 ms) no longer costs the call.  Host-buffer entry point: the call itself runs again with the four-launch tail and
+    returns the reference table.  Device entry point: a caller that synchronises its stream without the library sees
+    GSMCAL_E_HIP in the status column of the stalled stream and no other; gsmcal_sync() runs the call again and every row is
+    the reference's."""
+    import torch
+    raw = np.stack([g.synth.make_stream(dongle=d, num_frames=102)[0] for d in range(40, 48)])
+    ref = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC)
+    monkeypatch.setenv("GSMCAL_TEST_FUSED_STALL", str(stage))
+    monkeypatch.setenv("GSMCAL_FUSED_POLL_S", "0.05")
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        cx = g.Context(0, stream=st.cuda_stream)
+        monkeypatch.delenv("GSMCAL_TEST_FUSED_STALL")
+        monkeypatch.delenv("GSMCAL_FUSED_POLL_S")
+        try:
+            out = g.calibrate_batch(raw, setup["coef"], setup["ts"], FC, ctx=cx)
+            assert cx.fused_tail_reruns() == 1
+            assert np.array_equal(out["table"], ref["table"], equal_nan=True)
+            assert all(np.array_equal(a, b) for a, b in zip(ref["pos_info"], out["pos_info"]))
+            raw_t = torch.from_numpy(raw).to(dev)
+            tab = torch.zeros((8, g.TABLE_COLS), dtype=torch.float64, device=dev)
+            pos = torch.zeros((8, 2, g.MAX_POS_ROWS), dtype=torch.float64, device=dev)
+            g.calibrate_batch_dev(raw_t.data_ptr(), 8, raw.shape[1] // 2, setup["coef"], setup["ts"], FC, tab.data_ptr(), pos.data_ptr(), ctx=cx)
+            st.synchronize()                                        # (not gsmcal_sync: the time-out shows)
+            t = tab.cpu().numpy()
+            assert t[0, 9] == -2.0, t[:, 9]                         # GSMCAL_E_HIP in the stalled stream's row ...
+            assert np.array_equal(t[1:], ref["table"][1:], equal_nan=True)   # ... and only there
+            cx.sync()                                               # the library's synchronisation runs the call again
+            assert cx.fused_tail_reruns() == 2
+            assert np.array_equal(tab.cpu().numpy(), ref["table"], equal_nan=True)
+            pk = pos.cpu().numpy()
+            for i in range(8):
+                assert np.array_equal(pk[i, :, :int(ref["table"][i, 7])].T, ref["pos_info"][i]), i
+            fused, _ = cx.fused_tail_stats()
+            assert fused == 2                                       # (the two re-runs took the four-launch tail)
+        finally:
+            cx.close()
+
+
 def test_window_snrs_computed_inside_the_scan_kernel_are_the_table_kernels(g, setup, monkeypatch):
     """Throughput batches build no SNR table in HBM: k_coarse_scan<.., INL> computes the moving search's 3 579 window SNRs into
     its LDS copy itself.  Forced here on a small batch (GSMCAL_SNR_FULL=0) and written out on request
