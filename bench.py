@@ -78,13 +78,17 @@ def compute_roofline(regime, streams, n_samples, ntaps, seconds_per_step, mode="
            "valu_issue_util": None}
     try:
         with open(VALU_FILE) as fh:
-            v = json.load(fh).get(regime)
-        if v:
+            vf = json.load(fh)
+        v = vf.get(regime)
+        ok, note = _profile_is_current(vf)
+        if v and not ok:
+            out["valu_source"] = note
+        elif v:
             n = float(v["valu_wave_instr_per_step"])
             out["valu_wave_instr_per_step"] = int(n)
             out["valu_issue_util"] = round(n / VALU_ISSUE_PEAK / seconds_per_step, 4)
             out["valu_per_useful_flop_lane"] = round(n * 64 / flop, 3)
-            out["valu_source"] = os.path.relpath(VALU_FILE, ROOT) + " (committed rocprofv3 SQ pass of this configuration; not measured in this run)"
+            out["valu_source"] = os.path.relpath(VALU_FILE, ROOT) + f" (committed rocprofv3 SQ pass of this configuration; {note}; not measured in this run)"
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -709,6 +713,20 @@ def event_pass(ctx, fn, steps, torch, dev, filt=None):
     return {k: v for k, v in prof.items() if v[1]}
 
 
+def _profile_is_current(prof):
+    """(ok, note): a committed counter summary describes the kernels in the tree iff the source hash tools/profile.sh recorded
+    next to it equals the hash of csrc/ + include/gsmcal.h now (VERDICT r5 #4)."""
+    import gsmcal
+    have = prof.get("csrc_sha256")
+    if have is None:
+        return False, "the committed profile carries no source hash (made before round 6)"
+    if have != gsmcal.build.csrc_hash():
+        sys.stderr.write("bench.py: STALE PROFILE -- the committed counter passes describe other kernels than the ones in the tree; "
+                         "roofline.traffic / valu_* are withheld (run tools/profile.sh)\n")
+        return False, "STALE: the committed counter passes were taken on other kernel sources than the ones in the tree"
+    return True, f"kernels at commit {prof.get('git_commit', '?')}, source hash {have[:12]}"
+
+
 def pmc_traffic(kernel, D, N):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
     runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  NOT measured in this run."""
@@ -718,9 +736,12 @@ def pmc_traffic(kernel, D, N):
         pmc = json.load(f)
     if pmc.get("streams_per_gpu") != D or pmc.get("samples_per_stream") != N:
         return None, "committed PMC pass is for another batch shape"
+    ok, note = _profile_is_current(pmc)
+    if not ok:
+        return None, note
     for k, v in pmc.get("hbm_bytes_per_launch", {}).items():
         if k.startswith(kernel[:12]):
-            return v, os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+            return v, os.path.relpath(PMC_FILE, ROOT) + f" (rocprofv3 --pmc passes of this command, committed; {note}; not measured in this run)"
     return None, "kernel not in the committed PMC pass"
 
 
@@ -733,10 +754,13 @@ def pmc_step_traffic(D, N):
         pmc = json.load(f)
     if pmc.get("streams_per_gpu") != D or pmc.get("samples_per_stream") != N:
         return None, "committed PMC pass is for another batch shape"
+    ok, note = _profile_is_current(pmc)
+    if not ok:
+        return None, note
     per = {k: v for k, v in pmc.get("hbm_bytes_per_launch", {}).items() if k.startswith("k_") and k != "k_make_twiddles"}
     if not per:
         return None, "no chain kernels in the committed PMC pass"
-    return int(sum(per.values())), os.path.relpath(PMC_FILE, ROOT) + " (sum over the chain's kernels of the committed rocprofv3 --pmc passes of this command; not measured in this run)"
+    return int(sum(per.values())), os.path.relpath(PMC_FILE, ROOT) + f" (sum over the chain's kernels of the committed rocprofv3 --pmc passes of this command; {note}; not measured in this run)"
 
 
 def time_calib(torch, gsmcal, dev, ctx, raw_t, N, coef, ts, fc, K, W):

@@ -17,6 +17,21 @@ def _deps():
     return d
 
 
+def csrc_hash():
+    """SHA-256 over the library's sources (csrc/*, include/gsmcal.h, in name order): recorded by tools/profile.sh next to the
+    committed PMC / SQ summaries, compared by bench.py and tests/test_abi_cpu.py -- a profile that describes other kernels than
+    the ones in the tree is reported as stale, never quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(HERE, "csrc")
+    for f in sorted(os.listdir(src)):
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(HERE, "..", "include", "gsmcal.h"), "rb") as fh:
+        h.update(b"gsmcal.h\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if os.environ.get("GSMCAL_LIB"):                 # another build was asked for by name: it is loaded as it is, never rebuilt
         if not os.path.exists(LIB):

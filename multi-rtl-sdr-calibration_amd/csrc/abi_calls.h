@@ -700,6 +700,8 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     }
     c->cur = &c->lanes[0];
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
+    c->call_raw_fresh = (const void*)d_raw != c->last_raw;
+    c->last_raw = d_raw;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(ensure_head(c, decim));
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
@@ -801,6 +803,8 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     c->cur = &c->lanes[0];
     c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
+    c->call_raw_fresh = (const void*)d_raw != c->last_raw;
+    c->last_raw = d_raw;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(upload_cached(c, c->ts, c->h_ts, sch_ts, (size_t)2 * len_ts));
     RET_IF(upload_cached(c, c->cf, c->h_cf, carrier_freq, d));

@@ -69,6 +69,8 @@ struct gsmcal_ctx {
     int snr_inline_keep = 0;        // GSMCAL_SNR_INLINE_KEEP=1: ... and still writes the table out (gsmcal_last_batch_snr)
     int front_nt = -1;              // GSMCAL_FRONT_NT: non-temporal raw loads in k_front_fast (-1: by the size of the call, see front_fused())
     size_t call_raw_bytes = 0;      // raw bytes of the batch call in progress
+    const void* last_raw = nullptr; // raw buffer of the previous batch call: one that comes again may still sit in the Infinity Cache
+    bool call_raw_fresh = false;    // the call in progress reads another buffer than the previous call did
     int scan_split = 88;            // GSMCAL_SCAN_SPLIT: percent of a pipeline stage's captures in the first of its two front-kernel launches (0: one launch;
                                     // 12 800 captures: 0 / 70 / 80 / 88 / 94 -> 3.64 / 3.58 / 3.525 / 3.515 / 3.57 ms)
     int scan_stages = 0;            // GSMCAL_SCAN_STAGES: pipeline stages of a big scanner batch (0: by batch size)
@@ -806,7 +808,10 @@ int front_fused(gsmcal_ctx* c, const uint8_t* d_raw, int S, long n, const double
         // A smaller batch that the caller processes again (bench.py's 64 streams, 130 MB; 200 captures, 244 MiB) is served from the
         // Infinity Cache from the second step on and keeps plain loads: there nt costs 1 us of 22.6 / 4 us of 88.
         // GSMCAL_FRONT_NT=0/1 overrides.
-        const int nt = c->front_nt >= 0 ? c->front_nt : (c->call_raw_bytes > ((size_t)256 << 20) ? 1 : 0);
+        // Round 6: ... and so are the raw bytes of a call that reads ANOTHER buffer than the previous call did (a service fed by the
+        // ingest ring, bench.py's batch rotated over four buffers: nothing of it is in the Infinity Cache) -- 64 streams rotated
+        // over four buffers 0.1785 -> 0.1752 ms per step; the same buffer again keeps plain loads.
+        const int nt = c->front_nt >= 0 ? c->front_nt : ((c->call_raw_bytes > ((size_t)256 << 20) || c->call_raw_fresh) ? 1 : 0);
 #define FRONT_FAST(K) LAUNCH(c, K, dim3(nblk, S), dim3(256), flds, d_raw, 2 * n, (unsigned long long*)c->cur->partial.p + (size_t)s_off * nblk * 4 * 2, d_coef, nd, d_out, out_stride, nt)
         if (ntaps == 47) { if (sym) FRONT_FAST(k_front_fast47_sym); else FRONT_FAST(k_front_fast47); }
         else { if (sym) FRONT_FAST(k_front_fast31_sym); else FRONT_FAST(k_front_fast31); }

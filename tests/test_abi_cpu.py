@@ -191,3 +191,19 @@ def test_named_library_is_never_rebuilt_and_must_exist(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
     assert out.startswith("raised") and "absent.so" in out
     assert not (tmp_path / "absent.so").exists()
+
+
+def test_committed_counter_profiles_describe_the_kernels_in_the_tree():
+    """roofline.traffic / valu_* in bench.py's line are read from committed rocprofv3 counter passes.  The newest
+    ones must have been taken on exactly these sources: tools/profile.sh records the hash of csrc/ + include/gsmcal.h next to
+    them, and a kernel edit without a profile refresh turns this test red (bench.py then withholds the figures and says STALE)."""
+    import glob
+    import json
+    import gsmcal
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = gsmcal.build.csrc_hash()
+    for suffix in ("pmc_traffic.json", "valu_per_step.json"):
+        newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_" + suffix)))[-1]
+        with open(newest) as f:
+            prof = json.load(f)
+        assert prof.get("csrc_sha256") == want, f"{os.path.basename(newest)} was taken on other kernel sources: run tools/profile.sh and commit its summaries"

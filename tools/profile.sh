@@ -5,10 +5,11 @@
 # unprofiled default bench line, the N > 1 step cost on one rank (tools/dist_cost.py) and the clock / LDS micro-benchmark.
 # Raw .db files land in gpurun_out/; profiles/rocpd_summary.py turns them into the small files kept under profiles/.
 set -u
-RT=${1:-r05}     # round tag: prefixes every file written under profiles/ and gpurun_out/
+RT=${1:-r06}     # round tag: prefixes every file written under profiles/ and gpurun_out/
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+export GSMCAL_BENCH_NO_VARIANTS=1     # (the headline loop only: no depth-2 / one-buffer variants behind it)
 B="python3 $R/bench.py --no-cpu-baseline --no-sub --no-kernel-events --cache-streams /tmp/gsmcal_streams"
 CAL="$B --steps 20 --warmup 3"
 CALC="$CAL --prewarm-steps 0"     # counter passes: the counters do not depend on the clock state, and 256 fewer steps keep the .db files small
@@ -45,6 +46,21 @@ $P pmc $(db ${RT}_scan_fetch) $(db ${RT}_scan_write) profiles/${RT}_scan12800_pm
 $P sq $(db ${RT}_scan_sq) profiles/${RT}_scan12800_sq_counters.csv
 $P timeline $(db ${RT}_scan_stats) profiles/${RT}_scan12800_timeline.csv 72
 $P valu profiles/${RT}_valu_per_step.json calib_64=$(db ${RT}_sq):1 calib_1024=$(db ${RT}_big_sq):4 stream_mode_64=$(db ${RT}_str_sq):1 scan_12800=$(db ${RT}_scan_sq):s8
+# which kernels these counters describe: the source hash (bench.py and the CPU suite refuse a summary of other sources) and the
+# commit the tree was at when it was sent to the GPU box (written into profiles/.tree_commit before the gpurun call; the box has no .git)
+python3 - profiles/${RT}_pmc_traffic.json profiles/${RT}_scan12800_pmc_traffic.json profiles/${RT}_valu_per_step.json <<'PY'
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import gsmcal
+h = gsmcal.build.csrc_hash()
+commit = open("profiles/.tree_commit").read().strip() if os.path.exists("profiles/.tree_commit") else "unknown"
+for f in sys.argv[1:]:
+    if os.path.exists(f):
+        d = json.load(open(f))
+        d["csrc_sha256"] = h
+        d["git_commit"] = commit
+        json.dump(d, open(f, "w"), indent=1)
+PY
 python3 tools/dist_cost.py > profiles/${RT}_dist_cost.json 2> gpurun_out/${RT}_dist_cost.err
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/clock_fp64.hip -o /tmp/clock_fp64 && /tmp/clock_fp64 > profiles/${RT}_clock_lds_microbench.txt 2>&1   # (built here: no binary in the tree)
 mkdir -p gpurun_out/profiles_${RT} && cp profiles/${RT}_* gpurun_out/profiles_${RT}/
