@@ -107,6 +107,16 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
 void gsmcal_ctx_destroy(gsmcal_ctx* ctx);
 int gsmcal_sync(gsmcal_ctx* ctx);
 const char* gsmcal_last_error(gsmcal_ctx* ctx);
+/* The reference's console diagnostics.  The .m files disp() their intermediate results -- "FCCH coarse: hit successive
+ * 10 FCCH. pos ...", "FCCH fine: first round diff ...", "FCCH fine: FCCH freq ...", "SCH: sampling error ppm ...", the warnings of
+ * every early exit (FCCH_coarse_position.m:6,28,92-94, FCCH_fine_correction.m:6,13,66,96-99,116,156-161,190-193,
+ * SCH_corr_rate_correction.m:6,12,60,80,107-110,118, carrier_correct_post_SCH.m:6,11,17,73-79) -- and a MEX file that shadows one
+ * would otherwise run silent.  After gsmcal_FCCH_coarse_position / _FCCH_fine_correction / _SCH_corr_rate_correction /
+ * _carrier_correct_post_SCH this returns the lines that call's .m file would have printed, '\n'-separated, numbers formatted as
+ * MATLAB's num2str formats them (gsmcal_num2str: the same formatter, for row vectors).  buf may be NULL; the return value is the
+ * text's length without the terminator.  The gateway mexPrintf()s it; the Python mirror prints it when GSMCAL_VERBOSE=1. */
+long gsmcal_last_call_report(gsmcal_ctx* ctx, char* buf, size_t cap);
+long gsmcal_num2str(const double* x, int n, char* buf, size_t cap);
 const char* gsmcal_version(void);
 /* Pipelined batch calls (round 6).  gsm_sync_demod.m:107-124 is a serial chain per batch of dongles; a service that calibrates batch
  * after batch does not need batch i finished before batch i+1 starts.  With depth > 1, gsmcal_calibrate_batch_dev calls that run on

@@ -27,6 +27,7 @@
  * (reference sentinels) return normally with the sentinel outputs, as the .m files do.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gsmcal.h"
@@ -48,6 +49,16 @@ static gsmcal_ctx* ctx(void) {   /* created lazily, like the `persistent coef` o
 
 static void chk(int rc, const char* what) {
     if (rc < 0) mexErrMsgIdAndTxt("gsmcal:error", "%s failed (%d): %s", what, rc, gsmcal_last_error(g_ctx));
+}
+
+/* The .m file this MEX file shadows disp()s its intermediate results (FCCH_coarse_position.m:92-94, FCCH_fine_correction.m:66,
+ * 116,156-161,190, SCH_corr_rate_correction.m:80,118, carrier_correct_post_SCH.m:73-79, and a warning at every early exit): print
+ * the same lines, from the library's report of the call just made (getenv GSMCAL_QUIET=1: run silent). */
+static void say(void) {
+    char buf[8192];
+    const char* q = getenv("GSMCAL_QUIET");
+    if (q && q[0] == '1') return;
+    if (gsmcal_last_call_report(g_ctx, buf, sizeof(buf)) > 0) mexPrintf("%s", buf);
 }
 
 /* ---- the two complex-storage APIs behind one set of helpers ------------------------------------------------------ */
@@ -177,6 +188,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     int cnt = 0;
     chk(gsmcal_FCCH_coarse_position(ctx(), s, (long)n, (int)mxGetScalar(prhs[1]), pos, snr, GSMCAL_MAX_HITS, &cnt),
         "FCCH_coarse_position");
+    say();
     plhs[0] = mxCreateDoubleMatrix(1, cnt, mxREAL);
     memcpy(REAL_PTR(plhs[0]), pos, cnt * sizeof(double));
     if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, cnt, mxREAL); memcpy(REAL_PTR(plhs[1]), snr, cnt * sizeof(double)); }
@@ -191,6 +203,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     chk(gsmcal_FCCH_fine_correction(ctx(), s, (long)n, REAL_PTR(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
                                     (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), pos, GSMCAL_MAX_HITS, &npos,
                                     r, (long)n, &lr, &sp, &cp), "FCCH_fine_correction");
+    say();
     plhs[0] = mxCreateDoubleMatrix(1, npos, mxREAL);
     memcpy(REAL_PTR(plhs[0]), pos, npos * sizeof(double));
     if (nlhs > 1) plhs[1] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
@@ -209,6 +222,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     chk(gsmcal_SCH_corr_rate_correction(ctx(), s, (long)n, REAL_PTR(prhs[1]), (int)mxGetNumberOfElements(prhs[1]),
                                         ts, (int)nts, (int)mxGetScalar(prhs[3]), pi, GSMCAL_MAX_POS_ROWS, &rows,
                                         r, (long)n, &lr, &sp), "SCH_corr_rate_correction");
+    say();
     plhs[0] = mxCreateDoubleMatrix(rows, 2, mxREAL);
     for (i = 0; i < rows; ++i) {
         REAL_PTR(plhs[0])[i] = pi[i];
@@ -227,6 +241,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double* r = n ? (double*)mxMalloc(2 * n * sizeof(double)) : NULL;
     chk(gsmcal_carrier_correct_post_SCH(ctx(), s, (long)n, REAL_PTR(prhs[1]), rows, rows, (int)mxGetScalar(prhs[2]),
                                         mxGetScalar(prhs[3]), r, (long)n, &lr, &cp), "carrier_correct_post_SCH");
+    say();
     plhs[0] = lr < 0 ? scalar(-1.0) : cplx_col(r, (mwSize)lr);
     if (nlhs > 1) plhs[1] = scalar(cp);
     if (r) mxFree(r);
@@ -234,7 +249,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #elif defined(GSMCAL_FN_total_ppm_calculation)
     /* ppm_out = total_ppm_calculation(ppm_in) */
     double out;
-    gsmcal_total_ppm_calculation(REAL_PTR(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out);
+    if (gsmcal_total_ppm_calculation(REAL_PTR(prhs[0]), (int)mxGetNumberOfElements(prhs[0]), &out) == GSMCAL_S_ALL_INF)
+        mexPrintf("total PPM calculation: No valid PPM input!\n");          /* total_ppm_calculation.m:8 */
     plhs[0] = scalar(out);
 #elif defined(GSMCAL_FN_gsmcal_calibrate)
     /* [table, pos_info] = gsmcal_calibrate(s, coef, sch_training_sequence, freq)      gsm_sync_demod.m:107-124 for all dongles

@@ -15,4 +15,5 @@ from .api import (  # noqa: F401
     specific_fft_snr_fix_avg, FCCH_coarse_position, FCCH_fine_correction, SCH_corr_rate_correction,
     carrier_correct_post_SCH, total_ppm_calculation, SCH_equalise, frontend_batch, fcch_scan_batch, calibrate_batch,
     last_batch_details, last_batch_snr, TABLE_FIELDS, fcch_scan_batch_dev, calibrate_batch_dev, synth_expand_dev,
+    set_verbose, last_call_report, num2str,
 )

@@ -24,6 +24,8 @@ SIGNATURES = {
     "gsmcal_ctx_destroy": (None, [C.c_void_p]),
     "gsmcal_sync": (C.c_int, [C.c_void_p]),
     "gsmcal_last_error": (C.c_char_p, [C.c_void_p]),
+    "gsmcal_last_call_report": (C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "gsmcal_num2str": (C.c_long, [c_double_p, C.c_int, C.c_char_p, C.c_size_t]),
     "gsmcal_version": (C.c_char_p, []),
     "gsmcal_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gsmcal_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -29,6 +30,43 @@ from . import _lib
 from ._lib import MAX_HITS, MAX_POS_ROWS, TABLE_COLS, GsmcalError
 
 _CTX = {}
+
+
+_VERBOSE = [os.environ.get("GSMCAL_VERBOSE") == "1"]
+
+
+def set_verbose(on=True):
+    """Print the reference's console diagnostics (FCCH_coarse_position.m:92-94, FCCH_fine_correction.m:66,116,156-161,190, ...:
+    gsmcal_last_call_report) after every per-function call, as the .m files do.  Also switched on by GSMCAL_VERBOSE=1."""
+    _VERBOSE[0] = bool(on)
+
+
+def last_call_report(ctx=None):
+    """The lines the .m file of the most recent per-function call would have disp()ed (a str, '\\n'-separated)."""
+    ctx = ctx or default_context()
+    n = ctx.lib.gsmcal_last_call_report(ctx.h, None, 0)
+    if n <= 0:
+        return ""
+    buf = C.create_string_buffer(int(n) + 1)
+    ctx.lib.gsmcal_last_call_report(ctx.h, buf, len(buf))
+    return buf.value.decode()
+
+
+def num2str(x):
+    """MATLAB's num2str for a scalar / row vector, as the library formats its diagnostics (gsmcal_num2str)."""
+    v = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)).ravel())
+    lib = _lib.load()
+    n = lib.gsmcal_num2str(_dp(v), len(v), None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    lib.gsmcal_num2str(_dp(v), len(v), buf, len(buf))
+    return buf.value.decode()
+
+
+def _say(ctx):
+    if _VERBOSE[0]:
+        txt = last_call_report(ctx)
+        if txt:
+            print(txt, end="")
 
 
 class Context:
@@ -252,6 +290,7 @@ def FCCH_coarse_position(s, decimation_ratio, ctx=None):
     cnt = C.c_int()
     rc = ctx.check(ctx.lib.gsmcal_FCCH_coarse_position(ctx.h, _dp(buf), n, int(decimation_ratio), _dp(pos),
                                                        _dp(snr), MAX_HITS, C.byref(cnt)), "FCCH_coarse_position")
+    _say(ctx)
     if rc == 1:
         return -1.0, -1.0
     return pos[:cnt.value].copy(), snr[:cnt.value].copy()
@@ -279,6 +318,7 @@ def FCCH_fine_correction(s, base_position, oversampling_ratio, carrier_freq, ctx
                                                   float(carrier_freq), _dp(pos), MAX_HITS, C.byref(npos),
                                                   _dp(r) if want_r else None, len(r), C.byref(lr),
                                                   C.byref(sp), C.byref(cp)), "FCCH_fine_correction")
+    _say(ctx)
     fpos = pos[:npos.value].copy()
     if npos.value == 1 and fpos[0] == -1.0:
         fpos = -1.0
@@ -301,6 +341,7 @@ def SCH_corr_rate_correction(s, FCCH_pos, sch_training_sequence, oversampling_ra
                                                       len(fp), _dp(ts), len(ts), int(oversampling_ratio), _dp(pi),
                                                       MAX_POS_ROWS, C.byref(nrows), _dp(r) if want_r else None,
                                                       len(r), C.byref(lr), C.byref(sp)), "SCH_corr_rate_correction")
+    _say(ctx)
     pos_info = pi[:, :nrows.value].T.copy()
     rr = -1.0 if lr.value < 0 else (r[:lr.value] if want_r else lr.value)
     return pos_info, rr, sp.value
@@ -320,6 +361,7 @@ def carrier_correct_post_SCH(s, pos_info, oversampling_ratio, carrier_freq, ctx=
                                                       rows, rows, int(oversampling_ratio), float(carrier_freq),
                                                       _dp(r) if want_r else None, len(r), C.byref(lr), C.byref(cp)),
               "carrier_correct_post_SCH")
+    _say(ctx)
     rr = -1.0 if lr.value < 0 else (r[:lr.value] if want_r else lr.value)
     return rr, cp.value
 
@@ -352,6 +394,8 @@ def total_ppm_calculation(ppm_in):
     rc = lib.gsmcal_total_ppm_calculation(_dp(p), len(p), C.byref(out))
     if rc < 0:
         raise GsmcalError(f"total_ppm_calculation failed with {rc}")
+    if rc == 12 and _VERBOSE[0]:
+        print("total PPM calculation: No valid PPM input!")          # total_ppm_calculation.m:8
     return out.value
 
 

@@ -239,6 +239,27 @@ int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* c) { return c ? c->pipe_depth : GS
 
 const char* gsmcal_last_error(gsmcal_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+long gsmcal_last_call_report(gsmcal_ctx* c, char* buf, size_t cap) {
+    if (!c) return GSMCAL_E_ARG;
+    if (buf && cap > 0) {
+        const size_t n = c->report.size() < cap - 1 ? c->report.size() : cap - 1;
+        memcpy(buf, c->report.data(), n);
+        buf[n] = 0;
+    }
+    return (long)c->report.size();
+}
+
+long gsmcal_num2str(const double* x, int n, char* buf, size_t cap) {
+    if (!x || n < 0) return GSMCAL_E_ARG;
+    const std::string s = rep_num2str(x, n);
+    if (buf && cap > 0) {
+        const size_t m = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return (long)s.size();
+}
+
 int gsmcal_dev_alloc(gsmcal_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) return GSMCAL_E_ARG;
     ENTER(c);
@@ -440,8 +461,10 @@ int gsmcal_FCCH_coarse_position(gsmcal_ctx* c, const double* s, long len, int de
     memset(&a, 0, sizeof(a));
     a.mode = 0; a.decimation_ratio = decimation_ratio;
     StreamState st;
+    c->report.clear();
     RET_IF(coarse_api(c, s, len, a, &st));
     if (st.status < 0) return st.status;
+    c->report = report_coarse(st);
     if (st.n_coarse == 0) {
         position[0] = -1.0; snr[0] = -1.0; *count = 1;
         return GSMCAL_S_NO_FCCH;
@@ -471,10 +494,12 @@ int gsmcal_FCCH_fine_correction(gsmcal_ctx* c, const double* s, long len, const 
     c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_base > 0 ? num_base : 1;
+    c->report.clear();
     RET_IF(run_fine(c, 1, src, 0, g, H, false, -1, 0));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
+    c->report = report_fine(st, ov, c->params.fine_max_ppm, c->params.fine_gate_snr_db);
     if (sampling_ppm) *sampling_ppm = st.sampling_ppm1;
     if (carrier_ppm) *carrier_ppm = st.carrier_ppm1;
     if (st.fcch_is_sentinel) {
@@ -522,10 +547,12 @@ int gsmcal_SCH_corr_rate_correction(gsmcal_ctx* c, const double* s, long len, co
     c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
     const int H = num_fcch > 0 ? num_fcch : 1;
+    c->report.clear();
     RET_IF(run_sch(c, 1, src, 0, g, H, len_ts, false, -1));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
+    c->report = report_sch(st, ov, c->params.sch_max_ppm);
     if (sampling_ppm) *sampling_ppm = st.sampling_ppm2;
     if (st.n_rows == 0) {
         // the reference's all -1 sentinel keeps the shape of the exit taken: [-1 -1] (:9, :61) or the -ones(3K,2)
@@ -583,10 +610,12 @@ int gsmcal_carrier_correct_post_SCH(gsmcal_ctx* c, const double* s, long len, co
     RET_IF(push_states(c, v));
     c->last_S = 1; c->cur = &c->lanes[0]; c->lanes[0].lo = 0; c->lanes[0].n = 1; c->n_lanes_used = 1;
     Source src{SRC_ARR, nullptr, 0, (const cplx*)c->arr_in.p, len, nullptr, 0};
+    c->report.clear();
     RET_IF(run_post(c, 1, src, 0, g, nfcch > 0 ? nfcch : 1, false, nullptr, nullptr, nullptr));
     RET_IF(fetch_states(c, 1, v));
     const StreamState& st = v[0];
     if (st.status < 0) return st.status;
+    c->report = report_post(st);
     if (carrier_ppm) *carrier_ppm = st.carrier_ppm2;
     long lr = st.r3_kind == 3 ? st.op[1].n : -1;
     if (len_r) *len_r = lr;

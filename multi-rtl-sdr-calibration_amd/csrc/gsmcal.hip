@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -33,6 +34,7 @@
 #define TILE 1024
 
 #include "host_plan.h"
+#include "abi_report.h"
 
 // ================================================================================================
 // C ABI (include/gsmcal.h)

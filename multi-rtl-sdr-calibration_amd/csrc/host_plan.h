@@ -38,6 +38,7 @@ struct gsmcal_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    std::string report;             // console text the reference's function would have printed in the last per-function call (abi_report.h)
     Lane lanes[MAX_LANES];
     Lane* cur = nullptr;        // lane the helpers below enqueue on
     int n_lanes_cfg = 4;        // GSMCAL_LANES: upper bound; a lane gets at least 64 streams (measured: 128 streams 325 / 343 Gsample/s with

@@ -34,6 +34,7 @@ double* mxGetDoubles(const mxArray*);
 mxComplexDouble* mxGetComplexDoubles(const mxArray*);
 mxUint8* mxGetUint8s(const mxArray*);
 #endif
+int mexPrintf(const char* fmt, ...);
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray* mxCreateDoubleScalar(double v);
 mxArray* mxCreateLogicalScalar(mxLogical v);

@@ -130,6 +130,8 @@ void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...) { (void)id; (void)f
 int gsmcal_ctx_create(int d, gsmcal_ctx** o) { (void)d; (void)o; return -1; }
 void gsmcal_ctx_destroy(gsmcal_ctx* c) { (void)c; }
 const char* gsmcal_last_error(gsmcal_ctx* c) { (void)c; return ""; }
+long gsmcal_last_call_report(gsmcal_ctx* c, char* b, size_t n) { (void)c; (void)b; (void)n; return 0; }
+int mexPrintf(const char* fmt, ...) { (void)fmt; return 0; }
 int gsmcal_total_ppm_calculation(const double* in, int n, double* out) { (void)in; (void)n; *out = 0; return 0; }
 int main(void) {
     mwSize n = 0, i;
@@ -207,3 +209,15 @@ def test_committed_counter_profiles_describe_the_kernels_in_the_tree():
         with open(newest) as f:
             prof = json.load(f)
         assert prof.get("csrc_sha256") == want, f"{os.path.basename(newest)} was taken on other kernel sources: run tools/profile.sh and commit its summaries"
+
+
+def test_num2str_formats_like_matlab():
+    """The console diagnostics (gsmcal_last_call_report) format numbers with the library's restatement of MATLAB's num2str for row
+    vectors: integers as %{digits+2}d, everything else as %{d+7}.{d}g with d = max(floor(log10(max|x|)) + 5, 5), trimmed.
+    Known MATLAB answers (documentation examples and the forms the reference's disp() lines produce)."""
+    import gsmcal
+    want = {(3.14159265,): "3.1416", (1, 2, 3): "1  2  3", (67708.333, 67710.125): "67708.333       67710.125", (-12.3456,): "-12.3456",
+            (1e-5,): "1e-05", (100000,): "100000", (99999, 100000, -5): "99999   100000       -5", (0.001234,): "0.001234",
+            (12500, 13750, 12500): "12500  13750  12500", (-1,): "-1", (34.78260869565217,): "34.7826"}
+    for x, s_ in want.items():
+        assert gsmcal.num2str(list(x)) == s_, (x, gsmcal.num2str(list(x)))
