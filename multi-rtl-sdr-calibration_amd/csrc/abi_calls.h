@@ -830,7 +830,8 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
                              c->tw_n == g.nfft && c->head_epoch == c->coef_epoch;
     if (!pipelined || !same_inputs) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
-    c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;
+    c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;      // (also what an earlier call that failed half-way may have left set)
+    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     c->call_raw_fresh = (const void*)d_raw != c->last_raw;
     c->last_raw = d_raw;

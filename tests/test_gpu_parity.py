@@ -717,14 +717,18 @@ def test_wide_batch_of_distinct_streams_every_row_against_the_oracle(g, setup, n
     assert n_cal > n_streams // 2, "most of the mixed draw should calibrate"
 
 
-@pytest.mark.parametrize("forced_graphs", [False, True])
+@pytest.mark.parametrize("forced_graphs", [False, True, "pipelined"])
 def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_graphs):
     """the fused tail (k_post_chain_r: workgroups exchange results INSIDE one launch) with other tenants on the
     GPU.  Two contexts on two streams, 200 64-stream steps each, enqueued from two host threads, while a third context keeps
     the CUs busy with 1 600-capture scanner batches: every table identical to the single-context reference, no negative
     status, bounded wall time; and the library never had two fused tails in flight at once (the later caller of an overlapping
     pair took the four-launch tail: gsmcal_fused_tail_stats).  forced_graphs: the same with GSMCAL_GRAPH=2 -- every call replayed
-    from a captured graph whose fused tail passes the gate at each replay (a busy gate sends that call through eager launches)."""
+    from a captured graph whose fused tail passes the gate at each replay (a busy gate sends that call through eager launches).
+    "pipelined" (round 6): both contexts at gsmcal_ctx_set_pipeline_depth(2) -- two calls in flight inside EACH context, on its
+    internal streams, into alternating output sets -- under the same gate."""
+    pipelined = forced_graphs == "pipelined"
+    forced_graphs = forced_graphs is True
     import threading
     import time
     distinct = np.stack([g.synth.make_stream(dongle=8200 + d, num_frames=61)[0] for d in range(8)])
@@ -743,19 +747,28 @@ def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_g
     def calib(k):
         try:
             cx = ctxs[k]
-            d_raw, d_tab, d_pos = cx.alloc(raw.nbytes), cx.alloc(64 * g.TABLE_COLS * 8), cx.alloc(64 * 2 * g.MAX_POS_ROWS * 8)
+            d_raw = cx.alloc(raw.nbytes)
+            d_tab = [cx.alloc(64 * g.TABLE_COLS * 8) for _ in range(2)]
+            d_pos = [cx.alloc(64 * 2 * g.MAX_POS_ROWS * 8) for _ in range(2)]
             cx.h2d(d_raw, raw)
             cx.sync()
+            if pipelined:
+                cx.set_pipeline_depth(2)
             got = []
             for step in range(200):
-                g.calibrate_batch_dev(d_raw, 64, n, setup["coef"], setup["ts"], FC, d_tab, d_pos, ctx=cx)
+                b = step & 1 if pipelined else 0
+                g.calibrate_batch_dev(d_raw, 64, n, setup["coef"], setup["ts"], FC, d_tab[b], d_pos[b], ctx=cx)
                 if step % 20 == 19:                                   # twenty steps in flight, then look
                     cx.sync()
-                    t = np.empty((64, g.TABLE_COLS))
-                    cx.d2h(t, d_tab)
-                    got.append(t)
+                    for bb in ((0, 1) if pipelined else (0,)):
+                        t = np.empty((64, g.TABLE_COLS))
+                        cx.d2h(t, d_tab[bb])
+                        if bb == 0:
+                            got.append(t)
+                        else:
+                            assert np.array_equal(t, got[-1], equal_nan=True)
             tables[k] = got
-            for p_ in (d_raw, d_tab, d_pos):
+            for p_ in [d_raw] + d_tab + d_pos:
                 cx.free(p_)
         except Exception as e:  # noqa: BLE001
             errs.append((k, repr(e)))
