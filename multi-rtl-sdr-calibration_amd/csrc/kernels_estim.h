@@ -1096,11 +1096,13 @@ struct PostChainArgs {
 // launch advances whenever the device gives it slots at all -- other tenants (another context's kernels, RCCL, a kernel
 // hogging the CUs) only delay it, like any kernel.  What could stop it is a SECOND spinning launch holding the slots this
 // one's next workgroups need while waiting for slots this one holds; the host therefore never has two fused tails of this
-// process in flight on one device (host_plan.h: fused_gate -- the later caller takes the four-launch tail).  The poll
-// limit below (~a minute) only keeps a logic error from hanging the queue for good; it is not part of normal operation.
+// process in flight on one device (host_plan.h: fused_gate -- the later caller takes the four-launch tail).  Another
+// PROCESS's fused tail is outside that gate: there the poll limit of pcr_exchange (PostChainArgs::poll_ticks, 3 s of the
+// 100 MHz counter) ends the wait, the stream's rows report GSMCAL_E_HIP, a pinned flag tells the host, and gsmcal_sync /
+// the host-buffer entry points run the call again as four launches (round 6; abi_calls.h: fused_recover).
 // (A take-over scheme -- a workgroup whose poll runs out computes the missing peer's window itself -- was built in round
 // 5 and dropped: every form of it (a loop around the stage bodies, a restart loop around the kernel, an out-of-line cold
-// helper) cost 0.9-1.5 KB of scratch per lane in a kernel that has 16 B, and a scratch frame that size delays the launch
+// helper) cost 0.9-1.5 KB of scratch per lane in a kernel that has none, and a scratch frame that size delays the launch
 // of every wave: NOTES_r05.md.)
 // ------------------------------------------------------------------------------------------------
 #define PCR_EMPTY 0xFFFFFFFFFFFFFFFFull
