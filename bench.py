@@ -113,10 +113,11 @@ def parse():
     ap.add_argument("--workload", choices=["calib", "scan"], default="calib",
                     help="calib: full FCCH+SCH chain (headline); scan: scanner path of multi_rtl_sdr_gsm_FCCH_scanner.m "
                          "(front end + FCCH_coarse_position + acceptance; use --frames 64 --streams 200)")
-    ap.add_argument("--pipeline-depth", type=int, default=1,
-                    help="gsmcal_ctx_set_pipeline_depth for the headline loop: consecutive steps in flight inside ONE context (the front end "
-                         "of step i+1 under the tail of step i; every step is the same full chain on its own output buffers).  1 (default) = one "
-                         "step at a time; the depth-2 figure is reported beside the headline as ms_per_step_pipeline_depth2")
+    ap.add_argument("--pipeline-depth", type=int, default=4,
+                    help="gsmcal_ctx_set_pipeline_depth for the headline loop: consecutive steps in flight inside ONE context, each the "
+                         "same full chain on its own internal stream, workspace and output set (default 4 = the device's hardware queues; "
+                         "the K steps are timed from the first launch to the host's fence behind the last).  1 = one step at a time: "
+                         "reported beside the headline as ms_per_step_depth1")
     ap.add_argument("--raw-buffers", type=int, default=4,
                     help="device copies of the raw batch the headline loop takes in turn (4 x 130 MB > the 256 MB Infinity Cache: every "
                          "raw byte comes from HBM proper, SURVEY 8d); 1 = re-read one buffer (reported as ms_per_step_llc_resident)")
@@ -377,7 +378,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = gsmcal.Context(local_rank, stream=stream.cuda_stream)
-    NBUF = 4
+    NBUF = max(4, min(8, args.pipeline_depth))          # output sets taken in turn: at least as many as steps may be in flight
     nraw = max(1, args.raw_buffers)
     cal = Calib(torch, gsmcal, dev, ctx, raw_t, N, args.mode, coef, ts, fc, zero_copy=not use_dist, nbuf=NBUF, nraw=nraw)
 
@@ -393,10 +394,15 @@ def main():
     # Steps in flight inside the one context (gsmcal_ctx_set_pipeline_depth): each step is the same full chain, on output set
     # k mod 4 and raw buffer k mod nraw; step k's table is complete when step k + depth is enqueued or at the fence.  With torch's
     # collective (it runs on torch's stream, not behind the call's last stage) or uneven shards (torch pad copies) the depth stays 1.
-    depth = max(1, min(4, args.pipeline_depth))
+    depth = max(1, min(8, args.pipeline_depth))
     if args.mode != "table" or (use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes))):
         depth = 1
     ctx.set_pipeline_depth(depth)
+    if use_dist and depth > 1 and gather_kind == "native":
+        # steps in flight: the collectives of ALL of them on ONE stream, in step order (gsmcal_allgather_table_async: the library's side
+        # stream behind an event on the step's own stream) -- never the same communicator on four streams at once
+        tg.reset("async")
+        gather_kind = "async"
 
     def step():
         k = nstep[0]
@@ -461,17 +467,14 @@ def main():
             same_ = all(bool(np.array_equal(cal.table(b).numpy(), table, equal_nan=True)) for b in range(NBUF))
             return round(1e3 * t_ / args.steps, 4), same_
         if depth > 1:
-            variants["ms_per_step_depth1"], s1 = timed_variant(1, nraw)
-            tables_identical = tables_identical and s1
-        else:
-            # two consecutive steps in flight inside the one context (gsmcal_ctx_set_pipeline_depth(2): front end of step i+1 on the
-            # context's stream, fine search + fused tail of step i on an internal stream) -- opt-in: measured within a few per cent
-            # of one step at a time (the fused tail and the fine search each fill the chip's registers and LDS: NOTES_r06)
-            variants["ms_per_step_pipeline_depth2"], s1 = timed_variant(2, nraw)
+            variants["ms_per_step_depth1"], s1 = timed_variant(1, nraw)          # one step at a time (fused tail), rotated input
             tables_identical = tables_identical and s1
         if nraw > 1:
-            variants["ms_per_step_llc_resident"], s2 = timed_variant(depth, 1)
+            variants["ms_per_step_llc_resident"], s2 = timed_variant(depth, 1)   # the headline's depth on ONE re-read raw buffer
             tables_identical = tables_identical and s2
+            if depth > 1:
+                variants["ms_per_step_llc_resident_depth1"], s3 = timed_variant(1, 1)   # the protocol of rounds 1-5
+                tables_identical = tables_identical and s3
         loop["nraw"] = nraw
     ctx.set_pipeline_depth(1)                                        # everything below (checks, event passes, sub-results): one call at a time
     cal.launch(last_b, r=0)

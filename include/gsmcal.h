@@ -119,16 +119,21 @@ long gsmcal_last_call_report(gsmcal_ctx* ctx, char* buf, size_t cap);
 long gsmcal_num2str(const double* x, int n, char* buf, size_t cap);
 const char* gsmcal_version(void);
 /* Pipelined batch calls (round 6).  gsm_sync_demod.m:107-124 is a serial chain per batch of dongles; a service that calibrates batch
- * after batch does not need batch i finished before batch i+1 starts.  With depth > 1, gsmcal_calibrate_batch_dev calls that run on
- * one lane (up to 127 streams) and do not ask for r_correct are cut into stages on internal HIP streams -- the front end and coarse
- * detector of call i+1 run underneath the fine search and fused tail of call i -- each call in one of `depth` workspaces.
+ * after batch does not need batch i finished before batch i+1 starts.  With depth D > 1, up to D consecutive
+ * gsmcal_calibrate_batch_dev calls that run on one lane (up to 127 streams) and do not ask for r_correct are in flight at once:
+ * call i runs on internal HIP stream i mod D, in workspace i mod D, with the four-launch tail (whose kernels never wait for each
+ * other), and the kernels of the calls in flight interleave on the GPU -- 64 streams x 1 020 000: 0.177 ms per call at depth 1,
+ * 0.148 at 3, 0.138 at 4 (the device schedules four hardware queues: more gain nothing).
  *   depth 1 (default): every call is complete in the context's stream order when it returns: the semantics of every earlier release.
- *   depth D > 1: the outputs of call i (table, pos_info, r_len) are complete in the context's stream order at the start of call
+ *   depth D = 2..8: the outputs of call i (table, pos_info, r_len) are complete in the context's stream order at the start of call
  *     i+D, or after gsmcal_sync(), or after ANY other entry point of this context (they all join the calls in flight first).  The
  *     raw bytes and output buffers of call i must stay untouched until then: give D consecutive calls distinct output buffers.
- *     gsmcal_allgather_table[_async] right behind a pipelined call is enqueued behind THAT call's last stage (the gathered
- *     table completes where the call's own outputs do).  gsmcal_last_batch_details describes the most recent call.
- * Results are identical at every depth (same kernels, same order per call).  Returns GSMCAL_E_ARG for depth < 1 or > 4. */
+ *     Each call starts behind whatever the context's stream held when it was made (its input is ordered like at depth 1).
+ *     gsmcal_allgather_table[_async] right behind a pipelined call is enqueued behind THAT call (the gathered table completes where
+ *     the call's own outputs do).  gsmcal_last_batch_details describes the most recent call.
+ * Results are identical at every depth (same kernels, same order per call).  Returns GSMCAL_E_ARG for depth < 1 or > 8.
+ * (GSMCAL_PIPE_STAGES=2|3 selects the staged forms of the first design -- a call cut into front end | fine search | fused tail on
+ * stage streams -- which measured no gain: INTEGRATION.md, profiles/NOTES_r06.md.) */
 int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* ctx, int depth);
 int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* ctx);
 /* Diagnostics of the batch path's fused tail (one launch for everything behind the fine search's chunk sweep: its workgroups

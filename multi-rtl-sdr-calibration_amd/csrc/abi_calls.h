@@ -108,6 +108,7 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (const char* e2 = getenv("GSMCAL_FUSED_POLL_S")) { if (atof(e2) > 0.0) c->fused_poll_s = atof(e2); }
     if (const char* e2 = getenv("GSMCAL_TEST_FUSED_STALL")) c->test_stall = atoi(e2);
     if (const char* e2 = getenv("GSMCAL_PIPE_STAGES")) c->pipe_stages = atoi(e2) >= 3 ? 3 : (atoi(e2) <= 1 ? 1 : 2);
+    if (const char* e2 = getenv("GSMCAL_PIPE_SIDE_FUSED")) c->pipe_side_fused = atoi(e2) != 0;
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
     if (ge && atoi(ge) == 2) c->graph_always = true;
@@ -831,7 +832,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     if (!pipelined || !same_inputs) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
     c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;      // (also what an earlier call that failed half-way may have left set)
-    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr;
+    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr; c->no_fuse_now = false;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     c->call_raw_fresh = (const void*)d_raw != c->last_raw;
     c->last_raw = d_raw;
@@ -861,8 +862,12 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->side_stream[slot], c->side_in[slot], 0));
             L.stream = c->side_stream[slot];
-            c->tail_wait = c->side_last_tail >= 0 && c->side_last_tail != slot ? c->side_tail[c->side_last_tail] : nullptr;
-            c->tail_record = c->side_tail[slot];
+            if (c->pipe_side_fused) {                      // (experiment switch of tools/pipe_ab.sh: fused tails, chained one behind the other)
+                c->tail_wait = c->side_last_tail >= 0 && c->side_last_tail != slot ? c->side_tail[c->side_last_tail] : nullptr;
+                c->tail_record = c->side_tail[slot];
+            } else {
+                c->no_fuse_now = true;
+            }
         } else {
             L.stream = c->stream;                                        // ---- stage 0: front end + coarse detector (:107,110,117)
         }
@@ -885,7 +890,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             if (rc >= 0) rc = run_post(c, d, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out);
         }
         const hipStream_t out_stream = L.stream;                         // (stage 1's stream, or stage 2's when the call hopped)
-        c->cf_lane = nullptr; c->xlane = nullptr; c->split_stream = nullptr;
+        c->cf_lane = nullptr; c->xlane = nullptr; c->split_stream = nullptr; c->no_fuse_now = false;
         if (nst == 1 && rc >= 0 && co.fused) c->side_last_tail = slot;
         c->tail_wait = nullptr; c->tail_record = nullptr;
         if (hipEventRecord(c->pipe_handover[slot][last_ev], out_stream) != hipSuccess) { c->err = "hipEventRecord (pipeline)"; rc = GSMCAL_E_HIP; }

@@ -106,17 +106,22 @@ struct gsmcal_ctx {
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
     // ---- pipelined batch calls (gsmcal_ctx_set_pipeline_depth; gsm_sync_demod.m:107-124 over consecutive batches) ----
-    // A calibration call on one lane is cut into stages (front end + coarse detector | fine search | fused tail), each stage of
-    // every call on its own HIP stream (stage 0 = the context's stream), consecutive stages of ONE call chained by events: the
-    // front end of call i+1 runs underneath the tail of call i.  Each of the `pipe_depth` calls that may be in flight works in a
-    // workspace of its own (pipe[slot]); all fused tails share lane 0's exchange block and sit on one stream, in call order.
-    static constexpr int PIPE_MAX_DEPTH = 4, PIPE_MAX_STAGES = 3;
+    // Up to `pipe_depth` consecutive single-lane calibration calls in flight, each in a workspace of its own (pipe[slot]).
+    // pipe_stages = 1 (default): WHOLE calls side by side, call i on internal stream i mod depth behind an event on the context's
+    // stream, every call with the FOUR-LAUNCH tail -- its kernels wait for nobody and hold no slot while idle, so the kernels of
+    // up to four calls interleave workgroup by workgroup as slots free up: 64 streams 0.177 -> 0.148 / 0.138 ms per call at depth
+    // 3 / 4 (more streams than the device's four hardware queues gain nothing).  pipe_stages = 2 / 3 (kept for the record,
+    // NOTES_r06): a call cut into stages (front end + coarse detector | fine search | fused tail) on stage streams chained by
+    // events, all fused tails on one stream sharing lane 0's exchange block -- no gain: the fused tail and the certificate
+    // each fill every CU's registers and LDS, nothing of the next call fits beside them.
+    static constexpr int PIPE_MAX_DEPTH = 8, PIPE_MAX_STAGES = 3;
     int pipe_depth = 1;             // 1: a call is complete in stream order when it returns (the semantics of every earlier release)
-    int pipe_stages = 2;            // GSMCAL_PIPE_STAGES: 2 = front | tail, 3 = front | fine search | fused tail
+    int pipe_stages = 1;            // GSMCAL_PIPE_STAGES: 1 = whole calls side by side (four-launch tails), 2 = front | tail, 3 = front | fine search | fused tail
+    bool pipe_side_fused = false;   // GSMCAL_PIPE_SIDE_FUSED=1 (experiment): side-by-side calls keep the fused tail, chained one behind the other
     Lane pipe[PIPE_MAX_DEPTH];
     hipStream_t pipe_stream[PIPE_MAX_STAGES] = {nullptr, nullptr, nullptr};   // [0] unused: stage 0 runs on the context's stream
     hipEvent_t pipe_handover[PIPE_MAX_DEPTH][PIPE_MAX_STAGES] = {};          // [slot][k]: end of stage k of the slot's call
-    bool pipe_pending[PIPE_MAX_DEPTH] = {false, false, false, false};         // the slot's call has not been joined into the context's stream yet
+    bool pipe_pending[PIPE_MAX_DEPTH] = {};                                   // the slot's call has not been joined into the context's stream yet
     unsigned long pipe_calls = 0;
     int pipe_last_slot = -1;        // slot of the most recent pipelined call, -1: none since the last join
     int pipe_last_stages = 0;
@@ -124,9 +129,10 @@ struct gsmcal_ctx {
     Lane* detail_lane = nullptr;    // the workspace gsmcal_last_batch_details / _snr read (pipelined call), nullptr: lanes[]
     hipStream_t split_stream = nullptr;   // run_fine(): behind the chunk sweep the call hops to this stream (third pipeline stage)
     hipEvent_t split_event = nullptr;
-    // GSMCAL_PIPE_STAGES=1: whole calls side by side, call i on internal stream i mod depth; only the fused tails are chained
-    // (tail i+1 waits for tail i: at most one in flight, as the gate demands of separate contexts)
-    hipStream_t side_stream[PIPE_MAX_DEPTH] = {nullptr, nullptr, nullptr, nullptr};
+    // side-by-side calls: call i on internal stream i mod depth.  (pipe_side_fused: the fused tails chained, tail i+1 behind tail i --
+    // at most one in flight, as the gate demands of separate contexts; measured slower than the four-launch tails, NOTES_r06)
+    hipStream_t side_stream[PIPE_MAX_DEPTH] = {};
+    bool no_fuse_now = false;             // the call being enqueued takes the four-launch tail whatever the batch size (side-by-side calls)
     hipEvent_t side_in[PIPE_MAX_DEPTH] = {}, side_tail[PIPE_MAX_DEPTH] = {};
     hipEvent_t tail_wait = nullptr, tail_record = nullptr;   // run_fine(): events around the fused tail's launch
     int side_last_tail = -1;              // slot whose fused tail was enqueued last (-1: none pending)
@@ -600,7 +606,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
             // progress rests on is not this calculation but in-order dispatch + fused_gate_enter() below (k_post_chain_r's header).
             const int variant = ref_geom ? 0 : 1;
             const int per_cu = lds <= 159 * 1024 && H <= MAXH ? post_chain_blocks_per_cu(c, variant, lds) : 0;
-            chain->fused = c->fuse_post && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && per_cu > 0 &&
+            chain->fused = c->fuse_post && !c->no_fuse_now && cert_ok && src.kind == SRC_RAW && lvl == 0 && next_sch_lvl == 2 && per_cu > 0 &&
                            (long)H * S <= (long)per_cu * c->n_cu && c->n_lanes_used == 1;
             if (chain->fused) {
                 // k_post_chain_r's exchange block [S][2 parities][4 stages][MAXH][2] and launch counters [S]: the layout

@@ -725,8 +725,8 @@ def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_g
     status, bounded wall time; and the library never had two fused tails in flight at once (the later caller of an overlapping
     pair took the four-launch tail: gsmcal_fused_tail_stats).  forced_graphs: the same with GSMCAL_GRAPH=2 -- every call replayed
     from a captured graph whose fused tail passes the gate at each replay (a busy gate sends that call through eager launches).
-    "pipelined" (round 6): both contexts at gsmcal_ctx_set_pipeline_depth(2) -- two calls in flight inside EACH context, on its
-    internal streams, into alternating output sets -- under the same gate."""
+    "pipelined" (round 6): both contexts at gsmcal_ctx_set_pipeline_depth(4) -- four calls in flight inside EACH context, on its
+    internal streams, into four output sets in turn."""
     pipelined = forced_graphs == "pipelined"
     forced_graphs = forced_graphs is True
     import threading
@@ -748,19 +748,19 @@ def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_g
         try:
             cx = ctxs[k]
             d_raw = cx.alloc(raw.nbytes)
-            d_tab = [cx.alloc(64 * g.TABLE_COLS * 8) for _ in range(2)]
-            d_pos = [cx.alloc(64 * 2 * g.MAX_POS_ROWS * 8) for _ in range(2)]
+            d_tab = [cx.alloc(64 * g.TABLE_COLS * 8) for _ in range(4)]
+            d_pos = [cx.alloc(64 * 2 * g.MAX_POS_ROWS * 8) for _ in range(4)]
             cx.h2d(d_raw, raw)
             cx.sync()
             if pipelined:
-                cx.set_pipeline_depth(2)
+                cx.set_pipeline_depth(4)
             got = []
             for step in range(200):
-                b = step & 1 if pipelined else 0
+                b = step & 3 if pipelined else 0
                 g.calibrate_batch_dev(d_raw, 64, n, setup["coef"], setup["ts"], FC, d_tab[b], d_pos[b], ctx=cx)
                 if step % 20 == 19:                                   # twenty steps in flight, then look
                     cx.sync()
-                    for bb in ((0, 1) if pipelined else (0,)):
+                    for bb in ((0, 1, 2, 3) if pipelined else (0,)):
                         t = np.empty((64, g.TABLE_COLS))
                         cx.d2h(t, d_tab[bb])
                         if bb == 0:
@@ -804,7 +804,10 @@ def test_two_contexts_and_a_cu_hog_share_the_gpu(g, setup, monkeypatch, forced_g
             assert np.array_equal(t, ref["table"], equal_nan=True), f"context {k}: table differs from the single-context reference"
             assert np.all(t[:, 9] >= 0)
     fused, fell = sum(s_[0] for s_ in stats), sum(s_[1] for s_ in stats)
-    assert fused + fell == 400 and fused >= 1, stats
+    if pipelined:
+        assert fused == 0 and fell == 0, stats           # (side-by-side calls take the four-launch tail: the gate is never asked)
+    else:
+        assert fused + fell == 400 and fused >= 1, stats
     print(f"two contexts + hog: {wall:.2f} s, fused launches {stats[0][0]} + {stats[1][0]}, gate fall-backs {stats[0][1]} + {stats[1][1]}")
 
 
@@ -852,14 +855,14 @@ def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setu
     for i in range(64):
         parity.compare_stream(orcs[i], out["table"][i], det, i, out["pos_info"][i])
     # ... and the same batch through PIPELINED calls (gsmcal_ctx_set_pipeline_depth): eight consecutive
-    # gsmcal_calibrate_batch_dev calls in flight two / three / four deep, in two and in three stages, each into its own output
-    # set -- every table, pos_info and r_len bit for bit what the one-call-at-a-time path returned, and last_batch_details
-    # describes the last call
+    # gsmcal_calibrate_batch_dev calls in flight two to eight deep -- whole calls side by side with the four-launch tail (stages "1",
+    # the default) and the staged forms with the fused tail ("2", "3") -- each into its own output set: every table, pos_info and
+    # r_len bit for bit what the one-call-at-a-time path returned, and last_batch_details describes the last call
     import torch
     dev = torch.device("cuda", 0)
     raw_t = torch.from_numpy(raw).to(dev)
     n = raw.shape[1] // 2
-    for stages, depth in (("2", 2), ("3", 3), ("3", 2), ("2", 4), ("1", 2), ("1", 3)):
+    for stages, depth in (("1", 2), ("1", 4), ("1", 3), ("1", 8), ("2", 2), ("3", 3), ("3", 2), ("2", 4)):
         os.environ["GSMCAL_PIPE_STAGES"] = stages
         st = torch.cuda.Stream(device=dev)
         try:
@@ -885,7 +888,7 @@ def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setu
                 for key in det:
                     assert np.array_equal(np.asarray(det_p[key]), np.asarray(det[key]), equal_nan=True), key
                 fused, fell = cx.fused_tail_stats()
-                assert fused == 8 and fell == 0
+                assert fused == (0 if stages == "1" else 8) and fell == 0
                 # depth back to 1 mid-way: joins, then behaves as ever
                 cx.set_pipeline_depth(1)
                 g.calibrate_batch_dev(raw_t.data_ptr(), 64, n, setup["coef"], setup["ts"], FC, tabs[0].data_ptr(), ctx=cx)
