@@ -387,14 +387,15 @@ def main():
     # before a buffer is written again two steps later (gsmcal.dist.TableGatherer; uneven shards are padded).
     # N > 1: the C ABI's own all-gather, in line on the chain's stream (GSMCAL_BENCH_GATHER=async: on the library's side stream;
     # =torch: torch.distributed's collective, round 3's path) -- tools/dist_cost.py has what each costs per step on one rank
-    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, gsmcal.TABLE_COLS) if use_dist else (None, "none", None, None)
-    host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
+    NG = 4                                               # gather buffer pairs: as many as steps may be in flight (the async collective has four slots)
+    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, gsmcal.TABLE_COLS, pairs=NG) if use_dist else (None, "none", None, None)
+    host_gath = [torch.zeros((sum(sizes), gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(NG)] if use_dist else None
     nstep = [0]
     loop = {"nraw": nraw}
     # Steps in flight inside the one context (gsmcal_ctx_set_pipeline_depth): each step is the same full chain, on output set
     # k mod 4 and raw buffer k mod nraw; step k's table is complete when step k + depth is enqueued or at the fence.  With torch's
     # collective (it runs on torch's stream, not behind the call's last stage) or uneven shards (torch pad copies) the depth stays 1.
-    depth = max(1, min(8, args.pipeline_depth))
+    depth = max(1, min(8 if not use_dist else NG, args.pipeline_depth))
     if args.mode != "table" or (use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes))):
         depth = 1
     ctx.set_pipeline_depth(depth)
@@ -407,7 +408,7 @@ def main():
     def step():
         k = nstep[0]
         nstep[0] += 1
-        b, g = k % NBUF, k & 1
+        b, g = k % NBUF, k % NG
         if use_dist:
             tg.wait(g)
         cal.launch(b, r=k % loop["nraw"])
@@ -419,7 +420,7 @@ def main():
     def fence():
         ctx.sync()                                                   # (joins the steps still in flight on the library's stage streams)
         if use_dist:
-            for g in range(2):
+            for g in range(NG):
                 if tg.work[g] is not None:
                     host_gath[g].copy_(tg.rows(g), non_blocking=True)   # gathered table to the host (every rank)
         torch.cuda.synchronize(dev)
@@ -452,7 +453,7 @@ def main():
         elapsed = float(tt[0].item())
         elapsed_cold = float(tt[1].item()) if elapsed_cold is not None else None
     last_b = (nstep[0] - 1) % NBUF
-    last = (nstep[0] - 1) & 1                                        # (gather buffer pair of the last step)
+    last = (nstep[0] - 1) % NG                                       # (gather buffer pair of the last step)
     table = cal.table(last_b).numpy().copy()
     # every output set of the loop holds the same table: the steps in flight did not disturb each other
     tables_identical = all(bool(np.array_equal(cal.table(b).numpy(), table, equal_nan=True)) for b in range(min(NBUF, nstep[0])))
@@ -637,7 +638,7 @@ COLLECTIVE_NAMES = {"none": "none", "native": "all_gather(table): gsmcal_allgath
                     "torch": "all_gather(table): torch.distributed over RCCL"}
 
 
-def setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, cols):
+def setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, cols, pairs=2):
     """The table gatherer of an N > 1 run, for either workload (calibration table: 10 columns; scanner table: snr, num_hit).
     Which collective: decided in gsmcal.dist.choose_gatherer, identically on every rank.  The native communicator is set up
     and one CHECKED trial exchange runs on it (both buffer pairs, every peer's block compared), each under a time-out; if
@@ -657,7 +658,7 @@ def setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, co
             holder["comm"] = gdist.native_comm_from_process_group(ctx, dev, unique_id=uid) if uid is not None else None
             if holder["comm"] is None:
                 raise RuntimeError("rank 0 could not draw an RCCL unique id")
-            return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, cols, dev, mode="async" if want == "async" else "inline", stream=stream)
+            return gdist.NativeTableGatherer(ctx, holder["comm"], sizes, cols, dev, mode="async" if want == "async" else "inline", stream=stream, pairs=pairs)
 
     def verify(g):
         # BOTH placements the autotune may switch to, each on a throw-away context and stream of its own: a trial
@@ -673,7 +674,7 @@ def setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, co
                     vstream.synchronize()
                     vctx.close()
 
-    tg, kind, fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, cols, dev), dev,
+    tg, kind, fallback = gdist.choose_gatherer(make_native, lambda: gdist.TableGatherer(sizes, cols, dev, pairs=pairs), dev,
                                                want=want, verify=verify, timeout_s=float(os.environ.get("GSMCAL_BENCH_NATIVE_TIMEOUT_S", "90")))
     return tg, kind, (holder.get("comm") if kind != "torch" else None), fallback
 

@@ -50,18 +50,20 @@ class TableGatherer:
     collective on pair b, `wait(b)` completes it and `rows(b)` returns the table in global unit order.  Works on any
     torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests)."""
 
-    def __init__(self, sizes, cols, device, dtype=None, group=None):
+    def __init__(self, sizes, cols, device, dtype=None, group=None, pairs=2):
+        """pairs: send / receive buffer pairs taken in turn (2: the gather of step i under step i+1; more when more steps are in flight)"""
         import torch
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        self.pairs = int(pairs)
         self.sizes = list(sizes)
         self.world = len(self.sizes)
         self.rank = dist.get_rank(group)
         self.mx = max(self.sizes)
         dtype = dtype or torch.float64
-        self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
-        self.work = [None, None]
+        self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(self.pairs)]
+        self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(self.pairs)]
+        self.work = [None] * self.pairs
 
     def post(self, b, local):
         if local.shape[0] != self.sizes[self.rank]:
@@ -91,7 +93,7 @@ class TableGatherer:
         return self.recv[b][off: off + self.sizes[self.rank]]
 
     def reset(self, mode=None):
-        for b in range(2):
+        for b in range(self.pairs):
             self.wait(b)
 
 
@@ -141,13 +143,16 @@ class NativeTableGatherer:
     gsmcal_allgather_table_async -- the collective on the library's side stream behind an event, the gather of step i under
     the kernels of step i+1, at the price of that event (+14 us per step, tools/dist_cost.py)."""
 
-    def __init__(self, ctx, comm, sizes, cols, device, mode="inline", dtype=None, stream=None):
+    def __init__(self, ctx, comm, sizes, cols, device, mode="inline", dtype=None, stream=None, pairs=2):
         """`stream`: the torch stream that wraps the context's HIP stream (default: torch's current stream at construction).
         The collective is enqueued by the library on the CONTEXT's stream, the pad copies and the re-assembly of uneven shards
         by torch: both must be the same stream or the copy races the all-gather -- checked here when the context
         knows its stream, and every torch operation of this class runs inside `torch.cuda.stream(stream)`."""
         import torch
         self.ctx, self.comm, self.mode = ctx, comm, mode
+        self.pairs = int(pairs)
+        if not 1 <= self.pairs <= 4:
+            raise ValueError("NativeTableGatherer: 1..4 buffer pairs (gsmcal_allgather_table_async has four slots)")
         self.sizes = list(sizes)
         self.world, self.rank = len(self.sizes), comm.rank
         self.mx = max(self.sizes)
@@ -164,9 +169,9 @@ class NativeTableGatherer:
         if self.stream is not None and ctx_stream is not None and int(self.stream.cuda_stream) != int(ctx_stream):
             raise ValueError("NativeTableGatherer: the torch stream is not the context's stream -- pad copies would race the collective")
         with self._on_stream():
-            self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(2)]
-            self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(2)]
-        self.work = [None, None]
+            self.send = [torch.full((self.mx, cols), float("nan"), dtype=dtype, device=device) for _ in range(self.pairs)]
+            self.recv = [torch.zeros((self.world * self.mx, cols), dtype=dtype, device=device) for _ in range(self.pairs)]
+        self.work = [None] * self.pairs
 
     def _on_stream(self):
         import contextlib
@@ -221,7 +226,7 @@ class NativeTableGatherer:
     def reset(self, mode=None):
         """forget the posted buffers (between two timing trials) and optionally switch the placement of the collective; a
         collective still in flight on the side stream is waited for first (the context's stream is ordered behind it)"""
-        for b in range(2):
+        for b in range(self.pairs):
             if self.work[b] is not None and self.mode == "async":
                 self.ctx.check(self.ctx.lib.gsmcal_allgather_wait(self.ctx.h, b), "gsmcal_allgather_wait")
             self.work[b] = None
@@ -312,14 +317,15 @@ def verify_gatherer(tg, cols, device, sync, timeout_s=60.0):
                       for r, n in enumerate(tg.sizes)], dim=0)
     n = tg.sizes[tg.rank]
     local = (1000.0 * tg.rank + torch.arange(n, dtype=torch.float64).reshape(n, 1) + torch.arange(cols, dtype=torch.float64).reshape(1, cols) / 16.0).to(device)
-    for b in range(2):
+    npairs = getattr(tg, "pairs", 2)
+    for b in range(npairs):
         tg.post(b, local)
     import contextlib
     on_stream = tg._on_stream() if hasattr(tg, "_on_stream") else contextlib.nullcontext()
     with on_stream:                                           # (the clones run on the stream the gatherer's own torch work runs on)
-        got = [tg.rows(b).clone() for b in range(2)]
+        got = [tg.rows(b).clone() for b in range(npairs)]
     call_with_timeout(sync, timeout_s)
-    for b in range(2):
+    for b in range(npairs):
         if not torch.equal(got[b].cpu(), want):
             raise RuntimeError(f"trial all-gather returned a wrong table on rank {tg.rank} (buffer pair {b})")
         tg.work[b] = None
