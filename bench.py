@@ -399,11 +399,9 @@ def main():
     if args.mode != "table" or (use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes))):
         depth = 1
     ctx.set_pipeline_depth(depth)
-    if use_dist and depth > 1 and gather_kind == "native":
-        # steps in flight: the collectives of ALL of them on ONE stream, in step order (gsmcal_allgather_table_async: the library's side
-        # stream behind an event on the step's own stream) -- never the same communicator on four streams at once
-        tg.reset("async")
-        gather_kind = "async"
+    # (steps in flight at N > 1: the in-line collective of step k rides on step k's own internal stream, and the library chains the
+    # collectives of consecutive steps by events -- one communicator never runs two of them at once; which combination of depth and
+    # placement is fastest is measured below, max over ranks)
 
     def step():
         k = nstep[0]
@@ -441,10 +439,27 @@ def main():
     # line on the chain's stream (costs RCCL's small-message latency per step: 1.6 us on one rank, unknown over xGMI) or on the
     # library's side stream behind an event (costs ~14 us per step on one rank, hides the collective under the next step).  Both
     # timed over 40 steps, max over ranks, every rank takes the same decision.
+    # Round 6: with steps in flight (depth > 1) the choice has a third candidate -- one step at a time with the collective in line, the
+    # round-5 configuration: on ONE rank the collective's event traffic costs the pipelined loop more than the overlap gains (0.19-0.23
+    # against 0.18 ms), over xGMI nobody has measured; whichever is fastest, max over ranks, is what the timed loop runs.
     autotune = None
     if use_dist and gather_kind == "native" and "GSMCAL_BENCH_GATHER" not in os.environ:
-        autotune = gdist.autotune_placement(tg, lambda mode: time_steps(torch, dev, step, 40, 4, fence) / 40, dev)
-        gather_kind = "native" if autotune["chosen"] == "inline" else "async"
+        cands = [f"inline_depth{depth}", f"async_depth{depth}"] + (["inline_depth1"] if depth > 1 else [])
+
+        def configure(label):
+            mode, d_ = label.split("_depth")
+            fence()
+            tg.reset(mode)
+            ctx.set_pipeline_depth(int(d_))
+
+        def measure(label):
+            configure(label)
+            return time_steps(torch, dev, step, 40, 4, fence) / 40
+        autotune = gdist.autotune_choice(cands, measure, dev)
+        configure(autotune["chosen"])
+        mode_, d_ = autotune["chosen"].split("_depth")
+        gather_kind = "native" if mode_ == "inline" else "async"
+        depth = int(d_)
         nstep[0] = 0
     elapsed = time_steps(torch, dev, step, args.steps, args.warmup, fence)
     if use_dist:

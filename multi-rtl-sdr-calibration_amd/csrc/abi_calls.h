@@ -166,6 +166,8 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
     for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
         if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    for (hipEvent_t e : c->ag_chain)
+        if (e) (void)hipEventDestroy(e);
     if (c->ag_stream) (void)hipStreamSynchronize(c->ag_stream);
     for (int i = 0; i < gsmcal_ctx::AG_SLOTS; ++i) {
         if (c->ag_ready[i]) (void)hipEventDestroy(c->ag_ready[i]);

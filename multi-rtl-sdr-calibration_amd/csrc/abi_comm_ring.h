@@ -211,12 +211,19 @@ int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local,
     // behind a pipelined batch call the collective rides on the stream that call's table is written on (its last stage), and the
     // gathered table is complete where the call's own outputs are: `depth` calls later in the context's stream order, or gsmcal_sync
     const hipStream_t st = pipe_out_stream(c);
+    if (st != c->stream && c->ag_chain_n > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ag_chain[(c->ag_chain_n - 1) & 1], 0));   // behind the previous call's collective
     const ncclResult_t r = a->AllGather(d_local, d_all, (size_t)rows_per_rank * cols, ncclDouble, g->comm, st);
     if (r != ncclSuccess) {
         c->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "failed");
         return GSMCAL_E_HIP;
     }
-    if (st != c->stream) HIPCHK(c, hipEventRecord(c->pipe_handover[c->pipe_last_slot][gsmcal_ctx::PIPE_MAX_STAGES - 1], st));
+    if (st != c->stream) {
+        hipEvent_t& ev = c->ag_chain[c->ag_chain_n & 1];
+        if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToDevice));
+        HIPCHK(c, hipEventRecord(ev, st));
+        ++c->ag_chain_n;
+        HIPCHK(c, hipEventRecord(c->pipe_handover[c->pipe_last_slot][gsmcal_ctx::PIPE_MAX_STAGES - 1], st));   // the call's completion now includes its collective
+    }
     return 0;
 }
 

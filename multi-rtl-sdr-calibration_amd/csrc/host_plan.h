@@ -154,6 +154,10 @@ struct gsmcal_ctx {
     hipStream_t ag_stream = nullptr;
     hipEvent_t ag_ready[AG_SLOTS] = {nullptr, nullptr, nullptr, nullptr}, ag_done[AG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool ag_posted[AG_SLOTS] = {false, false, false, false};
+    // in-line collectives behind pipelined calls sit on those calls' streams -- different ones: an event chain keeps the collectives of
+    // one communicator one behind the other on the GPU (RCCL does not allow two of them to run at once)
+    hipEvent_t ag_chain[2] = {nullptr, nullptr};
+    int ag_chain_n = 0;
     // profiling
     bool prof = false;
     std::string prof_filter;

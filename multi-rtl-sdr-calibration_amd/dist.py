@@ -308,6 +308,21 @@ def autotune_placement(tg, measure, device="cpu", group=None, margin=0.98, modes
     return out
 
 
+def autotune_choice(labels, measure, device="cpu", group=None, margin=0.98):
+    """The fastest of several configurations, decided by measurement, identically on every rank.  `measure(label)` puts the job into
+    configuration `label` and returns seconds per step on THIS rank (called in the same order on every rank: it contains collectives);
+    the MAX over ranks of each figure decides, and a later label must beat the best so far by `margin` to displace it (the first
+    label is the default).  Returns {"<label>_ms_per_step": ..., "chosen": label}."""
+    worst = {m: all_max(measure(m), device, group) for m in labels}
+    chosen = labels[0]
+    for m in labels[1:]:
+        if worst[m] < margin * worst[chosen]:
+            chosen = m
+    out = {f"{m}_ms_per_step": round(1e3 * worst[m], 4) for m in labels}
+    out["chosen"] = chosen
+    return out
+
+
 def verify_gatherer(tg, cols, device, sync, timeout_s=60.0):
     """One checked exchange on both buffer pairs of a gatherer before the job commits to it: rank r sends rows filled with
     1000 r + row + col/16, every rank checks every peer's block.  `sync()` must complete the work enqueued so far (and may

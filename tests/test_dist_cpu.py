@@ -299,6 +299,49 @@ def test_every_rank_takes_the_same_collective_decision(scenario):
             assert a["tune"]["chosen"] == "inline"
 
 
+def _choice_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from gsmcal import dist as gd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the two ranks measure different favourites: the MAX over ranks decides, identically on both; a later label must win by the margin
+    cost = [{"inline_depth4": 0.230, "async_depth4": 0.140, "inline_depth1": 0.180},
+            {"inline_depth4": 0.150, "async_depth4": 0.260, "inline_depth1": 0.181}][rank]
+    seen = []
+
+    def measure(label):
+        seen.append(label)
+        dist.barrier()
+        return cost[label]
+    out = gd.autotune_choice(list(cost), measure, "cpu")
+    tie = gd.autotune_choice(["a", "b"], lambda m: {"a": 0.100, "b": 0.099}[m], "cpu")      # within the margin: the first stays
+    q.put((rank, (out, seen, tie)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_depth_and_placement_are_chosen_identically_on_every_rank():
+    """bench.py (N > 1, round 6): which of (collective in line | on the side stream) x (steps in flight | one at a time) the timed loop
+    runs is measured, max over ranks (gsmcal.dist.autotune_choice) -- two gloo ranks with opposite favourites end on the same one."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_choice_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    out, seen, tie = res[0]
+    assert seen == ["inline_depth4", "async_depth4", "inline_depth1"]
+    assert out == {"inline_depth4_ms_per_step": 230.0, "async_depth4_ms_per_step": 260.0, "inline_depth1_ms_per_step": 181.0, "chosen": "inline_depth1"}
+    assert tie["chosen"] == "a"
+
+
 def test_shard_ranges_cover_all_units():
     from gsmcal import dist as gd
     for u in (1, 7, 64, 102400):
