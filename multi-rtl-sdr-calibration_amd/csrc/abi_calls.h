@@ -822,11 +822,15 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     // Pipelined call (gsmcal_ctx_set_pipeline_depth > 1): table-mode calls that run on one lane.  Anything that would touch
     // what the calls in flight still read (new taps / training sequence / carrier frequencies, a workspace that must grow, the
     // twiddle table) joins them into the context's stream first.
-    bool pipelined = c->pipe_depth > 1 && !d_r_correct && !c->prof && c->stream != nullptr && plan_lanes(c, d) == 1;
+    const bool want_pipe = c->pipe_depth > 1 && !d_r_correct && c->stream != nullptr && plan_lanes(c, d) == 1;
+    bool pipelined = want_pipe && !c->prof;
     if (pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); pipelined = false; }
     }
+    // (events on every dispatch -- gsmcal_profile_enable -- or the caller's own stream capture: one call at a time, but with the
+    // kernels the pipelined calls run, so that a per-kernel profile of a depth-4 context describes what the depth-4 loop launches)
+    const bool same_kernels_unpipelined = want_pipe && !pipelined && c->pipe_stages == 1 && !c->pipe_side_fused;
     const bool same_inputs = (int)c->h_coef.size() == ntaps && memcmp(c->h_coef.data(), coef, (size_t)ntaps * sizeof(double)) == 0 &&
                              c->h_ts.size() == (size_t)2 * len_ts && memcmp(c->h_ts.data(), sch_ts, (size_t)2 * len_ts * sizeof(double)) == 0 &&
                              (int)c->h_cf.size() == d && memcmp(c->h_cf.data(), carrier_freq, (size_t)d * sizeof(double)) == 0 &&
@@ -834,7 +838,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     if (!pipelined || !same_inputs) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
     c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;      // (also what an earlier call that failed half-way may have left set)
-    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr; c->no_fuse_now = false;
+    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr; c->no_fuse_now = same_kernels_unpipelined;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     c->call_raw_fresh = (const void*)d_raw != c->last_raw;
     c->last_raw = d_raw;
@@ -968,6 +972,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     };
     const unsigned long long fused_before = c->n_fused_launches;
     RET_IF(run_maybe_graph(c, pick_slot(c, c->g_calib, key), key, enqueue, plan_lanes(c, d) > 1));
+    c->no_fuse_now = false;
     if (c->n_fused_launches != fused_before) record_fused_call(c, d_raw, d, n, ntaps, len_ts, d_table, d_pos_info, d_r_correct, d_r_len);
     plan_lanes(c, d);          // lane bookkeeping for gsmcal_last_batch_details (a replay does not run `enqueue`)
     c->cur = &c->lanes[0];

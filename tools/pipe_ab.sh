@@ -7,7 +7,8 @@ tag=${1:-pipe_ab}; shift
 out=gpurun_out/$tag
 mkdir -p "$out"
 B="python bench.py --no-sub --no-cpu-baseline --no-kernel-events --cache-streams /tmp/gsmcal_streams"
-for cfg in "${@:-1:1 2:1 3:1 4:1 6:1 8:1 2:2 3:3 4:1}"; do
+if [ $# -eq 0 ]; then set -- 1:1 2:1 3:1 4:1 5:1 6:1 8:1 2:2 3:3 4:1; fi
+for cfg in "$@"; do
   d=${cfg%%:*}; s=${cfg##*:}
   GSMCAL_PIPE_STAGES=$s $B --pipeline-depth "$d" >> "$out/d${d}_s${s}.json" 2>> "$out/d${d}_s${s}.err"
   echo "depth $d stages $s ${GSMCAL_PIPE_PRIO:-}: $(tail -1 "$out/d${d}_s${s}.json" | python -c 'import json,sys; r=json.loads(sys.stdin.read()); print({k: r[k] for k in r if k.startswith("ms_per_step") and not k.endswith("what")}, r["tables_identical"])')"
