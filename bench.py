@@ -191,7 +191,8 @@ class Calib:
         self.pos_ts = [torch.zeros((D, 2, gsmcal.MAX_POS_ROWS), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         self.rlen_ts = [torch.zeros((D,), dtype=torch.int64, device=dev) for _ in range(nbuf)]
         self.pos_t, self.rlen_t = self.pos_ts[0], self.rlen_ts[0]
-        self.r_t = torch.empty((D, N, 2), dtype=torch.float64, device=dev) if mode == "stream" else None
+        self.r_ts = [torch.empty((D, N, 2), dtype=torch.float64, device=dev) for _ in range(nbuf)] if mode == "stream" else None
+        self.r_t = self.r_ts[0] if self.r_ts else None
         self.host_table = [torch.zeros((D, gsmcal.TABLE_COLS), dtype=torch.float64).pin_memory() for _ in range(nbuf)]
         self.raws = [raw_t] + [raw_t.clone() for _ in range(nraw - 1)]
         dp = gsmcal._lib.c_double_p
@@ -205,7 +206,7 @@ class Calib:
                                             cp, len(self.coef), tp, len(self.ts), fp,
                                             C.c_void_p((self.host_table[b] if self.zero_copy else self.table_t[b]).data_ptr()),
                                             C.c_void_p(self.pos_ts[b].data_ptr()),
-                                            C.c_void_p(self.r_t.data_ptr()) if self.r_t is not None else None,
+                                            C.c_void_p(self.r_ts[b].data_ptr()) if self.r_ts is not None else None,
                                             C.c_void_p(self.rlen_ts[b].data_ptr()))
         ctx.check(rc, "gsmcal_calibrate_batch_dev")
 
@@ -396,7 +397,7 @@ def main():
     # k mod 4 and raw buffer k mod nraw; step k's table is complete when step k + depth is enqueued or at the fence.  With torch's
     # collective (it runs on torch's stream, not behind the call's last stage) or uneven shards (torch pad copies) the depth stays 1.
     depth = max(1, min(8 if not use_dist else NG, args.pipeline_depth))
-    if args.mode != "table" or (use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes))):
+    if use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes)):
         depth = 1
     ctx.set_pipeline_depth(depth)
     # (steps in flight at N > 1: the in-line collective of step k rides on step k's own internal stream, and the library chains the
@@ -888,19 +889,36 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
         torch.cuda.synchronize(dev)
     # the same streams with the corrected stream written (the API's real output, 18 B/sample)
     if args.mode == "table":
-        cs = Calib(torch, gsmcal, dev, ctx, cal.raw_t, N, "stream", coef, ts, fc)
+        sdepth = max(1, min(4, args.pipeline_depth))
+        cs = Calib(torch, gsmcal, dev, ctx, cal.raw_t, N, "stream", coef, ts, fc, nbuf=sdepth)
+        ks = [0]
 
-        def st():
-            cs.launch(0)
-            cs.to_host(0)
-        t = time_steps(torch, dev, st, max(3, K // 4), 2, prewarm_s=SUB_PREWARM_S) / max(3, K // 4)
+        def st():                                            # consecutive calls into output sets (table, pos_info, r_correct: 1 GB each) taken in turn
+            b = ks[0] % sdepth
+            ks[0] += 1
+            cs.launch(b)
+            cs.to_host(b)
+
+        def sfence():
+            ctx.sync()
+            torch.cuda.synchronize(dev)
+        ns = max(4, K // 4)
+        t1 = time_steps(torch, dev, st, ns, 2, sfence, prewarm_s=SUB_PREWARM_S) / ns          # one call at a time
+        t = t1
+        if sdepth > 1:                                       # calls in flight: the next call's table chain under this call's stream kernel
+            ctx.set_pipeline_depth(sdepth)
+            t = time_steps(torch, dev, st, ns, sdepth, sfence, prewarm_s=SUB_PREWARM_S) / ns
+            ctx.set_pipeline_depth(1)
         v = cal.D * N / t / 1e6
-        sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "Msample_per_s": round(v, 1),
+        same_r = all(bool(torch.equal(cs.r_ts[b], cs.r_ts[0])) for b in range(1, sdepth))
+        sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "ms_per_step_depth1": round(1e3 * t1, 4), "pipeline_depth": sdepth,
+                              "Msample_per_s": round(v, 1),
                               "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
                               "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4),
+                              "r_correct_identical_across_output_sets": same_r,
                               "roofline_compute": compute_roofline("stream_mode_64", cal.D, N, len(coef), t, mode="stream")}
         torch.cuda.synchronize(dev)
-        assert torch.equal(cs.table(0), cal.table(0)) or bool(torch.allclose(cs.table(0), cal.table(0), equal_nan=True))
+        assert all(torch.equal(cs.table(b), cal.table(0)) or bool(torch.allclose(cs.table(b), cal.table(0), equal_nan=True)) for b in range(sdepth))
         del cs
         torch.cuda.empty_cache()
     # scanner path: BASELINE config 3 (200 captures) and config 5 per GPU (12 800 captures, 16.4 GB, generated on the device)

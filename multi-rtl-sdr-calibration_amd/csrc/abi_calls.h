@@ -800,6 +800,27 @@ int gsmcal_fcch_scan_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     return 0;
 }
 
+// r_correct of the S streams of the current lane (gsm_sync_demod.m:118-120 hand it to SCH_demod): one launch on the lane's stream
+static int launch_r_correct(gsmcal_ctx* c, Lane& L, const Source& src, const uint8_t* raw_i, int S, long n, int ntaps, double* d_r_correct_lane) {
+    StreamTileArgs ta;
+    ta.raw = raw_i; ta.raw_stride = 2 * n; ta.coef = (const double*)c->coef.p; ta.ntaps = ntaps;
+    ta.dst = (cplx*)d_r_correct_lane; ta.dst_stream_stride = n;
+    const size_t tlds = stream_tile_lds(ntaps);
+    bool sym = (int)c->h_coef.size() == ntaps;         // exactly mirrored taps (what fir1 returns)
+    for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
+    if (ntaps == 47 && sym) {                           // the drivers' filter: taps in registers, every sample read once
+        LAUNCH(c, k_stream_tile_s47<ST47_TILE>, dim3((unsigned)((n + (long)ST47_TILE * ST_TPB - 1) / ((long)ST47_TILE * ST_TPB)), S), dim3(ST_THREADS), stream_tile_s47_lds(), (const StreamState*)L.state.p, ta);
+        CHECK_LAUNCH(c);
+    } else if (tlds <= 64 * 1024) {
+        LAUNCH_GEOM(ta.ntaps == 47, c, (k_stream_tile<47>), (k_stream_tile<0>), dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
+        CHECK_LAUNCH(c);
+    } else {                                        // very long filters: the general tile gather
+        const int tiles = (int)((n + TILE - 1) / TILE);
+        RET_IF(launch_gather(c, S, src, 4, TILE, true, tiles, (cplx*)d_r_correct_lane, n, 0));
+    }
+    return 0;
+}
+
 // (a call that took the fused tail: what fused_recover needs to run it again; the inputs are the context's cached copies)
 static void record_fused_call(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, int ntaps, int len_ts, double* d_table, double* d_pos_info,
                               double* d_r_correct, long* d_r_len) {
@@ -822,7 +843,8 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     // Pipelined call (gsmcal_ctx_set_pipeline_depth > 1): table-mode calls that run on one lane.  Anything that would touch
     // what the calls in flight still read (new taps / training sequence / carrier frequencies, a workspace that must grow, the
     // twiddle table) joins them into the context's stream first.
-    const bool want_pipe = c->pipe_depth > 1 && !d_r_correct && c->stream != nullptr && plan_lanes(c, d) == 1;
+    // (with r_correct only the side-by-side form: the staged forms put the tail on a stage stream the stream kernel would hold up)
+    const bool want_pipe = c->pipe_depth > 1 && (!d_r_correct || c->pipe_stages == 1) && c->stream != nullptr && plan_lanes(c, d) == 1;
     bool pipelined = want_pipe && !c->prof;
     if (pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -895,6 +917,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             rc = run_sch(c, d, src, 2, g, H, len_ts, true, 3);
             if (rc >= 0) rc = run_post(c, d, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out);
         }
+        if (rc >= 0 && d_r_correct) rc = launch_r_correct(c, L, src, d_raw, d, n, ntaps, d_r_correct);
         const hipStream_t out_stream = L.stream;                         // (stage 1's stream, or stage 2's when the call hopped)
         c->cf_lane = nullptr; c->xlane = nullptr; c->split_stream = nullptr; c->no_fuse_now = false;
         if (nst == 1 && rc >= 0 && co.fused) c->side_last_tail = slot;
@@ -947,24 +970,7 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             RET_IF(run_sch(c, S, src, 2, g, H, len_ts, true, 3));                           // :119 (+ post-SCH window setup)
             RET_IF(run_post(c, S, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out));   // :120, :123-124
         }
-        if (d_r_correct) {
-            StreamTileArgs ta;
-            ta.raw = raw_i; ta.raw_stride = 2 * n; ta.coef = (const double*)c->coef.p; ta.ntaps = ntaps;
-            ta.dst = (cplx*)d_r_correct + (size_t)lo * n; ta.dst_stream_stride = n;
-            const size_t tlds = stream_tile_lds(ntaps);
-            bool sym = (int)c->h_coef.size() == ntaps;         // exactly mirrored taps (what fir1 returns)
-            for (int k = 0; sym && k < ntaps / 2; ++k) sym = c->h_coef[k] == c->h_coef[ntaps - 1 - k];
-            if (ntaps == 47 && sym) {                           // the drivers' filter: taps in registers, every sample read once
-                LAUNCH(c, k_stream_tile_s47<ST47_TILE>, dim3((unsigned)((n + (long)ST47_TILE * ST_TPB - 1) / ((long)ST47_TILE * ST_TPB)), S), dim3(ST_THREADS), stream_tile_s47_lds(), (const StreamState*)L.state.p, ta);
-                CHECK_LAUNCH(c);
-            } else if (tlds <= 64 * 1024) {
-                LAUNCH_GEOM(ta.ntaps == 47, c, (k_stream_tile<47>), (k_stream_tile<0>), dim3((unsigned)((n + (long)ST_TILE * ST_TPB - 1) / ((long)ST_TILE * ST_TPB)), S), dim3(ST_THREADS), tlds, (const StreamState*)L.state.p, ta);
-                CHECK_LAUNCH(c);
-            } else {                                        // very long filters: the general tile gather
-                const int tiles = (int)((n + TILE - 1) / TILE);
-                RET_IF(launch_gather(c, S, src, 4, TILE, true, tiles, (cplx*)d_r_correct + (size_t)lo * n, n, 0));
-            }
-        }
+        if (d_r_correct) RET_IF(launch_r_correct(c, L, src, raw_i, S, n, ntaps, d_r_correct + (size_t)2 * lo * n));
     }
     c->cf_lane = nullptr;
     RET_IF(join_lanes(c, nl));

@@ -658,6 +658,42 @@ def test_stream_mode_kernels_agree_to_rounding_and_with_the_oracle_on_unaligned_
             stream_close(c["r_correct"][i, :L], a["r_correct"][i, :L])
 
 
+def test_pipelined_calls_with_the_corrected_stream(g, setup):
+    """Calls in flight (gsmcal_ctx_set_pipeline_depth) that also write r_correct: the next call's table chain runs under this call's
+    stream kernel.  Six calls three deep over two different raw batches, each into its own output set: table, r_len and every
+    sample of r_correct bit for bit what the one-call-at-a-time path wrote."""
+    import torch
+    dev = torch.device("cuda", 0)
+    raws = [np.stack([g.synth.make_stream(dongle=d, num_frames=61)[0] for d in ds]) for ds in ((20, 21, 22), (23, 24, 25))]
+    n = raws[0].shape[1] // 2
+    refs = [g.calibrate_batch(r_, setup["coef"], setup["ts"], FC, want_r=True) for r_ in raws]
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        cx = g.Context(0, stream=st.cuda_stream)
+        try:
+            raw_t = [torch.from_numpy(r_).to(dev) for r_ in raws]
+            tabs = [torch.zeros((3, g.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(6)]
+            rls = [torch.zeros((3,), dtype=torch.int64, device=dev) for _ in range(6)]
+            rcs = [torch.full((3, n, 2), float("nan"), dtype=torch.float64, device=dev) for _ in range(6)]
+            cx.set_pipeline_depth(3)
+            for k in range(6):
+                g.calibrate_batch_dev(raw_t[k & 1].data_ptr(), 3, n, setup["coef"], setup["ts"], FC, tabs[k].data_ptr(), None,
+                                      rcs[k].data_ptr(), rls[k].data_ptr(), ctx=cx)
+            cx.sync()
+            for k in range(6):
+                ref = refs[k & 1]
+                assert np.array_equal(tabs[k].cpu().numpy(), ref["table"], equal_nan=True), k
+                rl = rls[k].cpu().numpy()
+                assert np.array_equal(rl, ref["r_len"]), k
+                got = rcs[k].cpu().numpy()
+                for i in range(3):
+                    L = int(rl[i])
+                    if L > 0:
+                        assert np.array_equal(got[i, :L, 0] + 1j * got[i, :L, 1], ref["r_correct"][i, :L]), (k, i)
+        finally:
+            cx.close()
+
+
 def test_1024_stream_batch_on_staggered_lanes(g, setup):
     """1 024 streams in one call: four lanes of 256 whose front kernels follow one another (the default from 256 streams per lane
     on) -- every copy of a stream gets the row it gets in a batch of its own."""
