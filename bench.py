@@ -399,6 +399,8 @@ def main():
     depth = max(1, min(8 if not use_dist else NG, args.pipeline_depth))
     if use_dist and (gather_kind == "torch" or any(sz != Dmax for sz in sizes)):
         depth = 1
+    if args.mode == "stream" and "--pipeline-depth" not in " ".join(sys.argv):
+        depth = 1          # (with r_correct written the stream kernel saturates both pipes: calls in flight measured 0.60-0.62 against 0.585-0.589 ms)
     ctx.set_pipeline_depth(depth)
     # (steps in flight at N > 1: the in-line collective of step k rides on step k's own internal stream, and the library chains the
     # collectives of consecutive steps by events -- one communicator never runs two of them at once; which combination of depth and
@@ -903,15 +905,16 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
             ctx.sync()
             torch.cuda.synchronize(dev)
         ns = max(4, K // 4)
-        t1 = time_steps(torch, dev, st, ns, 2, sfence, prewarm_s=SUB_PREWARM_S) / ns          # one call at a time
-        t = t1
-        if sdepth > 1:                                       # calls in flight: the next call's table chain under this call's stream kernel
-            ctx.set_pipeline_depth(sdepth)
-            t = time_steps(torch, dev, st, ns, sdepth, sfence, prewarm_s=SUB_PREWARM_S) / ns
+        t = time_steps(torch, dev, st, ns, 2, sfence, prewarm_s=SUB_PREWARM_S) / ns           # one call at a time: the figure
+        tp = None
+        if sdepth > 1:                                       # calls in flight: the next call's table chain under this call's stream kernel --
+            ctx.set_pipeline_depth(sdepth)                   # no gain (the stream kernel saturates both pipes), reported beside it
+            tp = time_steps(torch, dev, st, ns, sdepth, sfence, prewarm_s=SUB_PREWARM_S) / ns
             ctx.set_pipeline_depth(1)
         v = cal.D * N / t / 1e6
         same_r = all(bool(torch.equal(cs.r_ts[b], cs.r_ts[0])) for b in range(1, sdepth))
-        sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "ms_per_step_depth1": round(1e3 * t1, 4), "pipeline_depth": sdepth,
+        sub["stream_mode"] = {"streams": cal.D, "ms_per_step": round(1e3 * t, 4), "pipeline_depth": 1,
+                              **({f"ms_per_step_pipeline_depth{sdepth}": round(1e3 * tp, 4)} if tp is not None else {}),
                               "Msample_per_s": round(v, 1),
                               "bytes_per_sample_algorithmic": 18, "path_GBps": round(v * 1e6 * 18 / 1e9, 1),
                               "path_frac_of_hbm": round(v * 1e6 * 18 / 1e9 / HBM_PEAK_GBS, 4),
