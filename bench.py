@@ -928,7 +928,7 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
     for name, ncap in (("config3_scan_200", 200), ("config5_scan_12800_per_gpu", 12800)):
         try:
             r = bench_scan(args, torch, gsmcal, dev, ctx, ncap, 64, distinct=32, steps=max(5, K // 2), warmup=2, cpu=(ncap == 200))
-            sub[name] = {k: r[k] for k in ("ms_per_step", "value", "hbm_GBps_algorithmic", "path_frac_of_hbm", "captures_with_hits",
+            sub[name] = {k: r[k] for k in ("ms_per_step", "ms_per_step_depth1", "pipeline_depth", "value", "hbm_GBps_algorithmic", "path_frac_of_hbm", "captures_with_hits",
                                            "kernels_ms_per_step_untimed_pass", "parity_checked_captures") if k in r}
             if "cpu_baseline" in r:     # BASELINE config 1: the CPU-only FCCH_coarse_position path on 640 000-sample captures
                 sub["config1_cpu_scan_path"] = dict(r["cpu_baseline"], what="config 1: raw2iq + fir1(30) + 1:64 + FCCH_coarse_position "
@@ -1067,29 +1067,36 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
     sizes = list(sizes) if sizes is not None else [D] * world
     gsmcal.synth_expand_dev(base_t.data_ptr(), nd, N, raw_t.data_ptr(), D, first_unit=first_unit, ctx=ctx)
     ctx.sync()
-    out_t = [torch.zeros((D, 2), dtype=torch.float64, device=dev) for _ in range(2)]
-    host_out = torch.zeros((D, 2), dtype=torch.float64).pin_memory()
-    host_gath = [torch.zeros((sum(sizes), 2), dtype=torch.float64).pin_memory() for _ in range(2)] if use_dist else None
+    NB = 4                                               # output sets / gather buffer pairs taken in turn: as many as calls may be in flight
+    out_t = [torch.zeros((D, 2), dtype=torch.float64, device=dev) for _ in range(NB)]
+    host_outs = [torch.zeros((D, 2), dtype=torch.float64).pin_memory() for _ in range(NB)]
+    host_gath = [torch.zeros((sum(sizes), 2), dtype=torch.float64).pin_memory() for _ in range(NB)] if use_dist else None
     cp = coef.ctypes.data_as(gsmcal._lib.c_double_p)
     nstep = [0]
+    # calls in flight inside the context (single-stage batches, i.e. below 1 200 captures: bigger ones are pipelines of stages inside
+    # ONE call already): the detector of call i under the front kernel of call i+1
+    pdepth = max(1, min(NB, args.pipeline_depth)) if D < 1200 and (not use_dist or all(sz == sizes[0] for sz in sizes)) else 1
+    if use_dist and type(tg).__name__ == "TableGatherer":
+        pdepth = 1                                           # (torch's collective runs on torch's stream, not behind the call it follows)
 
     def step():
         # single rank: the acceptance kernel stores (snr, num_hit) straight into pinned host memory (no copy queued).
-        # N > 1: the table stays in device memory, alternately in one of two buffers; the all-gather of step i (posted behind the
-        # kernels that fill buffer i & 1) overlaps the kernels of step i+1, the only wait is before a buffer is written again
-        b = nstep[0] & 1
+        # N > 1: the table stays in device memory, in one of four buffers in turn; the all-gather of step i (posted behind the
+        # kernels that fill buffer i mod 4) overlaps the kernels of the next steps, the only wait is before a buffer is written again
+        b = nstep[0] % NB
         nstep[0] += 1
         if use_dist:
             tg.wait(b)
-        dst_t = out_t[b] if use_dist else host_out
+        dst_t = out_t[b] if use_dist else host_outs[b]
         ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
                                                      C.c_void_p(dst_t.data_ptr()), None, None, None), "scan")
         if use_dist:
             tg.post(b, out_t[b])                                     # one RCCL all-gather of the (snr, num_hit) table
 
     def fence():
+        ctx.sync()                                                   # (joins the calls still in flight on the library's streams)
         if use_dist:
-            for b in range(2):
+            for b in range(NB):
                 if tg.work[b] is not None:
                     host_gath[b].copy_(tg.rows(b), non_blocking=True)   # the GATHERED table to the host (every rank)
         torch.cuda.synchronize(dev)
@@ -1097,13 +1104,20 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    elapsed = time_steps(torch, dev, step, steps, warmup, fence, prewarm_s=0.0 if use_dist else SUB_PREWARM_S)
+    elapsed1 = None
+    if pdepth > 1 and not use_dist:                                  # one call at a time first (reported beside the figure)
+        elapsed1 = time_steps(torch, dev, step, steps, warmup, fence, prewarm_s=SUB_PREWARM_S)
+    ctx.set_pipeline_depth(pdepth)
+    elapsed = time_steps(torch, dev, step, steps, warmup + pdepth - 1, fence, prewarm_s=0.0 if use_dist else SUB_PREWARM_S)
+    fence()
+    ctx.set_pipeline_depth(1)
+    host_out = host_outs[(nstep[0] - 1) % NB]
     gathered_ok = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        last = (nstep[0] - 1) & 1
+        last = (nstep[0] - 1) % NB
         res = out_t[last].cpu().numpy()
         # every rank checks every peer's block of the gathered table against that peer's own digest (independent gloo group)
         from gsmcal import dist as gdist
@@ -1116,7 +1130,8 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
     else:
         res = host_out.numpy().copy()
     value = sum(sizes) * N * steps / elapsed / 1e6
-    out = {"ms_per_step": round(1e3 * elapsed / steps, 4), "value": round(value, 3),
+    out = {"ms_per_step": round(1e3 * elapsed / steps, 4), "value": round(value, 3), "pipeline_depth": pdepth,
+           **({"ms_per_step_depth1": round(1e3 * elapsed1 / steps, 4)} if elapsed1 is not None else {}),
            "hbm_GBps_algorithmic": round(value * 1e6 * 2.25 / 1e9, 1),
            "path_frac_of_hbm": round(value * 1e6 * 2.25 / 1e9 / HBM_PEAK_GBS / world, 4),
            "captures_with_hits": int(np.sum(res[:, 1] > 0)),
@@ -1124,7 +1139,7 @@ def bench_scan(args, torch, gsmcal, dev, ctx, D, frames, distinct, steps, warmup
     if not args.no_kernel_events and rank == 0:
         def launch_only():                                   # (no collective in here: only rank 0 runs this pass)
             ctx.check(ctx.lib.gsmcal_fcch_scan_batch_dev(ctx.h, C.c_void_p(raw_t.data_ptr()), D, N, cp, len(coef),
-                                                         C.c_void_p((out_t[0] if use_dist else host_out).data_ptr()), None, None, None), "scan")
+                                                         C.c_void_p((out_t[0] if use_dist else host_outs[0]).data_ptr()), None, None, None), "scan")
         prof = event_pass(ctx, launch_only, steps, torch, dev)
         out["kernels_ms_per_step_untimed_pass"] = {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if D >= 1200:     # pipelined batch: stage k's detector and the tail of its front kernel run UNDER stage k+1's front kernel
@@ -1174,7 +1189,7 @@ def bench_scan_main(args, rank, world, dev, use_dist):
     D = sizes[rank]
     if D < 1:
         raise SystemExit("more ranks than captures")
-    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, 2) if use_dist else (None, "none", None, None)
+    tg, gather_kind, ncomm, gather_fallback = setup_gatherer(torch, gsmcal, gdist, ctx, dev, stream, local_rank, sizes, 2, pairs=4) if use_dist else (None, "none", None, None)
     r = bench_scan(args, torch, gsmcal, dev, ctx, D, args.frames, args.distinct, args.steps, args.warmup,
                    cpu=not args.no_cpu_baseline and world == 1, use_dist=use_dist, world=world, rank=rank, sizes=sizes, tg=tg, first_unit=first_unit)
     N = args.frames * 10000

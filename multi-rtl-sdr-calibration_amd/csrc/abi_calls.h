@@ -722,7 +722,7 @@ int gsmcal_frontend_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, cons
 int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long n, const double* coef, int ntaps,
                                double* d_snr_numhit, double* d_positions, double* d_pos_snr, int* d_counts) {
     if (!c || !d_raw || !coef || !d_snr_numhit || d < 1 || n < 1 || ntaps < 1) return GSMCAL_E_ARG;
-    ENTER(c);
+    HIPCHK(c, hipSetDevice(c->device));
     const int ov = 8, dec_ratio = 8, decim = ov * dec_ratio;   // ..FCCH_scanner.m:43-45
     const long nd = (n + decim - 1) / decim;
     if (hits_capacity(nd, dec_ratio) > MAXH) return GSMCAL_E_CAPACITY;
@@ -730,12 +730,58 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         c->err = "capture shorter than 23 frames after decimation (FCCH_coarse_position.m:25 would index past the end)";
         return GSMCAL_E_INDEX;
     }
+    // Calls in flight (gsmcal_ctx_set_pipeline_depth > 1, the side-by-side form): a single-stage scanner batch (up to 1 199 captures)
+    // runs on internal stream i mod depth in workspace i mod depth, so the detector of call i -- one resident round of latency-bound
+    // workgroups -- sits underneath the bandwidth-bound front kernel of call i+1 (multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,163-186
+    // over consecutive sweeps).  Same semantics as for calibration calls: outputs complete at call i + depth / gsmcal_sync / any other
+    // entry point.
+    bool pipelined = c->pipe_depth > 1 && c->pipe_stages == 1 && !c->prof && c->stream != nullptr && plan_lanes(c, d, false) == 1;
+    if (pipelined) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); pipelined = false; }
+    }
+    const bool same_taps = (int)c->h_coef.size() == ntaps && memcmp(c->h_coef.data(), coef, (size_t)ntaps * sizeof(double)) == 0 && c->head_epoch == c->coef_epoch;
+    if (!pipelined || !same_taps) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
+    c->detail_lane = nullptr;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     c->call_raw_fresh = (const void*)d_raw != c->last_raw;
     c->last_raw = d_raw;
     RET_IF(upload_cached(c, c->coef, c->h_coef, coef, ntaps));
     RET_IF(ensure_head(c, decim));
+    if (pipelined) {
+        RET_IF(pipe_prepare(c));
+        const int slot = (int)(c->pipe_calls % (unsigned long)c->pipe_depth);
+        const int last_ev = gsmcal_ctx::PIPE_MAX_STAGES - 1;
+        Lane& L = c->pipe[slot];
+        if (c->pipe_pending[slot]) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[slot][last_ev], 0));
+            c->pipe_pending[slot] = false;
+        }
+        HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream[slot], c->side_in[slot], 0));
+        L.stream = c->side_stream[slot];
+        L.lo = 0; L.n = d;
+        c->cur = &L;
+        c->n_lanes_used = 1;
+        int rc = ensure(c, L.dec, (size_t)d * nd * sizeof(cplx));
+        if (rc >= 0) rc = front_fused(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd, 0, d);
+        if (rc >= 0) {
+            ScanAccept acc;
+            acc.snr_numhit = d_snr_numhit; acc.positions = d_positions; acc.pos_snr = d_pos_snr; acc.counts = d_counts;
+            rc = coarse(c, d, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, true);
+        }
+        if (hipEventRecord(c->pipe_handover[slot][last_ev], L.stream) != hipSuccess) { c->err = "hipEventRecord (pipeline)"; rc = GSMCAL_E_HIP; }
+        c->pipe_pending[slot] = true;
+        c->pipe_last_slot = slot;
+        c->pipe_last_stages = 1;
+        ++c->pipe_calls;
+        c->detail_lane = &L;
+        c->cur = &c->lanes[0];
+        c->last_S = d;
+        if (rc < 0) { (void)pipe_drain(c); return rc; }
+        return 0;
+    }
     const std::vector<uintptr_t> key = {(uintptr_t)d_raw, (uintptr_t)d, (uintptr_t)n, (uintptr_t)ntaps,
                                         (uintptr_t)d_snr_numhit, (uintptr_t)d_positions, (uintptr_t)d_pos_snr,
                                         (uintptr_t)d_counts, (uintptr_t)c->n_lanes_cfg, (uintptr_t)c->params_epoch};
@@ -790,6 +836,7 @@ int gsmcal_fcch_scan_batch(gsmcal_ctx* c, const uint8_t* raw, int d, long n, con
     double* d_ps = d_pos + (size_t)d * MAXH;
     int* d_cnt = (int*)(d_ps + (size_t)d * MAXH);
     RET_IF(gsmcal_fcch_scan_batch_dev(c, (const uint8_t*)c->misc.p, d, n, coef, ntaps, d_sn, d_pos, d_ps, d_cnt));
+    RET_IF(pipe_join(c));                      // (a pipelined context: the copies below wait for this call like for any other)
     std::vector<double> sn((size_t)2 * d);
     HIPCHK(c, hipMemcpyAsync(sn.data(), d_sn, sn.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (positions) HIPCHK(c, hipMemcpyAsync(positions, d_pos, (size_t)d * MAXH * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -205,6 +205,43 @@ def test_bench_distributed_step_on_one_rank_and_its_fall_back(fail_native):
         assert "native RCCL" in cfg["collective"] and "collective_fallback_from_native" not in cfg
 
 
+def test_scanner_calls_in_flight_change_no_bit(g_mod, ctx):
+    """gsmcal_ctx_set_pipeline_depth for the scanner path (round 6): single-stage batches side by side on the context's internal
+    streams -- the detector of call i under the front kernel of call i+1.  Six calls three deep over two different capture sets, each
+    into its own outputs: snr / num_hit, hit positions, their SNRs and counts bit for bit the one-call-at-a-time outputs; a batch big
+    enough for the stage pipeline (joined, not pipelined) in between; and the host-buffer entry point on the pipelined context."""
+    import torch
+    g = g_mod
+    dev = torch.device("cuda", 0)
+    coef = g.synth.fir1(30, 200e3 / g.synth.FS)
+    sets = [np.stack([g.synth.make_stream(dongle=7300 + k, arfcn=i, num_frames=40, bcch=i % 3 != 2)[0] for i in range(24)]) for k in range(2)]
+    n = sets[0].shape[1] // 2
+    refs = [g.fcch_scan_batch(s_, coef, ctx=ctx) for s_ in sets]
+    H = g.MAX_HITS
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        cx = g.Context(0, stream=st.cuda_stream)
+        try:
+            raw_t = [torch.from_numpy(s_).to(dev) for s_ in sets]
+            outs = [(torch.zeros((24, 2), dtype=torch.float64, device=dev), torch.zeros((24, H), dtype=torch.float64, device=dev),
+                     torch.zeros((24, H), dtype=torch.float64, device=dev), torch.zeros((24,), dtype=torch.int32, device=dev)) for _ in range(6)]
+            cx.set_pipeline_depth(3)
+            for k in range(6):
+                sn, ps, pn, cn = outs[k]
+                g.fcch_scan_batch_dev(raw_t[k & 1].data_ptr(), 24, n, coef, sn.data_ptr(), ps.data_ptr(), pn.data_ptr(), cn.data_ptr(), ctx=cx)
+            cx.sync()
+            for k in range(6):
+                ref = refs[k & 1]
+                sn, ps, pn, cn = (t.cpu().numpy() for t in outs[k])
+                assert np.array_equal(sn[:, 0], ref["snr"], equal_nan=True) and np.array_equal(sn[:, 1], ref["num_hit"]), k
+                assert np.array_equal(ps, ref["positions"]) and np.array_equal(pn, ref["pos_snr"], equal_nan=True) and np.array_equal(cn, ref["counts"]), k
+            again = g.fcch_scan_batch(sets[1], coef, ctx=cx)            # host-buffer entry point, pipelined context: joins by itself
+            for key in ("snr", "num_hit", "positions", "pos_snr", "counts"):
+                assert np.array_equal(np.asarray(again[key]), np.asarray(refs[1][key]), equal_nan=True), key
+        finally:
+            cx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fail_native", [False, True])
 def test_bench_scan_workload_distributed_step_on_one_rank(fail_native):
