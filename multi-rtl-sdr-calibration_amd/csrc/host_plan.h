@@ -133,6 +133,9 @@ struct gsmcal_ctx {
     // at most one in flight, as the gate demands of separate contexts; measured slower than the four-launch tails, NOTES_r06)
     hipStream_t side_stream[PIPE_MAX_DEPTH] = {};
     bool no_fuse_now = false;             // the call being enqueued takes the four-launch tail whatever the batch size (side-by-side calls)
+                                          // ... and the SNR table of the moving search only (the hop walk on its own spectra): with calls in
+                                          // flight the full table's 27 MB and its screening pass cost more than the walk's latency saves
+                                          // (four deep, 100 steps: 0.1315 -> 0.1287 ms per call; one call at a time it is the other way round)
     hipEvent_t side_in[PIPE_MAX_DEPTH] = {}, side_tail[PIPE_MAX_DEPTH] = {};
     hipEvent_t tail_wait = nullptr, tail_record = nullptr;   // run_fine(): events around the fused tail's launch
     int side_last_tail = -1;              // slot whose fused tail was enqueued last (-1: none pending)
@@ -900,7 +903,7 @@ int coarse(gsmcal_ctx* c, int S, const cplx* d_dec, long stride, long len, int d
     // search's windows (at 200 captures the longer table kernel already costs what the shorter walk saves)
     long ntab = nwin;
     unsigned sblocks = (unsigned)((nwin + 255) / 256);
-    if (fft_len == 16 && 2 * S <= c->n_cu && c->snr_full && len - (fft_len - 1) > nwin) {
+    if (fft_len == 16 && 2 * S <= c->n_cu && c->snr_full && !c->no_fuse_now && len - (fft_len - 1) > nwin) {
         ntab = len - (fft_len - 1);
         a.snr_nwin = ntab;
         a.snr_screen_db = c->snr_screen_db;
