@@ -922,7 +922,12 @@ def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setu
                         assert np.array_equal(pk[i, :, :rows].T, out["pos_info"][i]), (stages, depth, k, i)
                     assert np.array_equal(rls[k].cpu().numpy(), rls[0].cpu().numpy())
                 for key in det:
-                    assert np.array_equal(np.asarray(det_p[key]), np.asarray(det[key]), equal_nan=True), key
+                    if key == "coarse_snr" and stages == "1":
+                        # (calls in flight walk the hops on their own spectra instead of the full SNR table: the hits' SNRs -- an
+                        # intermediate, compared with the oracle at the same bar elsewhere -- agree to rounding, everything else bit for bit)
+                        assert np.allclose(det_p[key], det[key], rtol=0.0, atol=parity.SNR_ATOL, equal_nan=True), key
+                    else:
+                        assert np.array_equal(np.asarray(det_p[key]), np.asarray(det[key]), equal_nan=True), key
                 fused, fell = cx.fused_tail_stats()
                 assert fused == (0 if stages == "1" else 8) and fell == 0
                 # depth back to 1 mid-way: joins, then behaves as ever
