@@ -120,10 +120,12 @@ long gsmcal_num2str(const double* x, int n, char* buf, size_t cap);
 const char* gsmcal_version(void);
 /* Pipelined batch calls (round 6).  gsm_sync_demod.m:107-124 is a serial chain per batch of dongles; a service that calibrates batch
  * after batch does not need batch i finished before batch i+1 starts.  With depth D > 1, up to D consecutive
- * gsmcal_calibrate_batch_dev calls that run on one lane (up to 127 streams) and do not ask for r_correct are in flight at once:
- * call i runs on internal HIP stream i mod D, in workspace i mod D, with the four-launch tail (whose kernels never wait for each
- * other), and the kernels of the calls in flight interleave on the GPU -- 64 streams x 1 020 000: 0.177 ms per call at depth 1,
- * 0.148 at 3, 0.138 at 4 (the device schedules four hardware queues: more gain nothing).
+ * gsmcal_calibrate_batch_dev calls that run on one lane (up to 127 streams) are in flight at once: call i runs on internal HIP
+ * stream i mod D, in workspace i mod D, with the four-launch tail (whose kernels never wait for each other), and the kernels of the
+ * calls in flight interleave on the GPU -- 64 streams x 1 020 000: 0.177 ms per call at depth 1, 0.148 at 3, 0.138 at 4 (the device
+ * schedules four hardware queues: more gain nothing; with r_correct written calls in flight are supported and gain nothing).  The
+ * same holds for single-stage gsmcal_fcch_scan_batch_dev calls (fewer than 1 200 captures; multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,
+ * 163-186 over consecutive sweeps): the detector of call i runs under the front kernel of call i+1 -- 200 captures 0.086 -> 0.068 ms.
  *   depth 1 (default): every call is complete in the context's stream order when it returns: the semantics of every earlier release.
  *   depth D = 2..8: the outputs of call i (table, pos_info, r_len) are complete in the context's stream order at the start of call
  *     i+D, or after gsmcal_sync(), or after ANY other entry point of this context (they all join the calls in flight first).  The
