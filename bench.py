@@ -46,6 +46,8 @@ def _newest_profile(suffix):
 
 PMC_FILE = _newest_profile("pmc_traffic.json")      # HBM bytes per launch from committed rocprofv3 --pmc passes
 VALU_FILE = _newest_profile("valu_per_step.json")   # wave-level VALU instructions per step from committed SQ passes
+STATS_FILE = PMC_FILE.replace("pmc_traffic.json", "kernel_stats.csv")                       # rocprofv3 --kernel-trace --stats of the headline loop
+STATS_ISO_FILE = PMC_FILE.replace("pmc_traffic.json", "kernel_stats_one_call_at_a_time.csv")  # ... of the same loop fenced behind every step
 
 
 def useful_flop_per_stream(n_samples, ntaps, n_windows=10, mode="table"):
@@ -123,6 +125,9 @@ def parse():
                          "raw byte comes from HBM proper, SURVEY 8d); 1 = re-read one buffer (reported as ms_per_step_llc_resident)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU-oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-in-flight", action="store_true",
+                    help="profiler passes: the headline loop's kernels (the depth it is set to) but the host fences behind every step, so that "
+                         "rocprofv3's per-kernel averages are those of a kernel that has the GPU to itself (tools/profile.sh); marked in the line")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed HIP-event passes (roofline kernel figure, breakdown)")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-results (config 2, stream mode, scanner path)")
     ap.add_argument("--cache-streams", default=None,
@@ -417,6 +422,8 @@ def main():
             tg.post(g, cal.table_t[b])                               # one RCCL all-gather of the ppm table
         else:
             cal.to_host(b)
+        if args.one_in_flight:
+            ctx.sync()
 
     def fence():
         ctx.sync()                                                   # (joins the steps still in flight on the library's stage streams)
@@ -538,7 +545,8 @@ def main():
         "ms_per_step_no_prewarm": round(1e3 * (elapsed_cold if elapsed_cold is not None else elapsed) / args.steps, 4),
         "ms_per_step_no_prewarm_what": "the same W + K steps, timed FIRST (before the pre-warm steps" + (" and before the placement autotune: "
                                        "collective in line" if use_dist else "") + "); the headline follows W + K + prewarm_steps earlier steps",
-        "pipeline_depth": depth,
+        "pipeline_depth": depth, **({"one_in_flight": "--one-in-flight: the host fenced behind every step (a profiler pass, not the headline)"}
+                                    if args.one_in_flight else {}),
         "input": (f"rotated over {nraw} buffers ({nraw} x {D * 2 * N / 1e6:.1f} MB: beyond the 256 MB Infinity Cache, every raw byte from HBM)"
                   if nraw > 1 else "one raw buffer re-read every step (served by the Infinity Cache)"),
         "tables_identical": tables_identical, **variants,
@@ -600,6 +608,12 @@ def main():
                                       "what": "the one HBM-streaming kernel: 2 B/sample raw read + 16/64 B/sample decimated write; "
                                               "HIP events on its own dispatch, second run of the same K steps (one call at a time, raw "
                                               f"batch rotated over {nraw} device buffers like the headline: HBM proper)"}
+                    rp = rocprof_kernel_avg_ms(k, D, N)
+                    if rp:
+                        roof["kernel"]["rocprofv3"] = {**rp, "what": "the committed rocprofv3 --kernel-trace --stats summaries of this command (tools/"
+                                                       "profile.sh, same sources): one_call_at_a_time = the loop fenced behind every step, the figure "
+                                                       "avg_launch_ms above must agree with; calls_in_flight = the headline loop itself, where the "
+                                                       f"kernel shares the chip with the kernels of up to {depth - 1} other calls and takes longer"}
                     if prof_llc and k in prof_llc and prof_llc[k][1]:
                         avg2 = prof_llc[k][0] / prof_llc[k][1]
                         roof["kernel"]["avg_launch_ms_llc_resident"] = round(avg2, 5)
@@ -773,6 +787,32 @@ def pmc_traffic(kernel, D, N):
         if k.startswith(kernel[:12]):
             return v, os.path.relpath(PMC_FILE, ROOT) + f" (rocprofv3 --pmc passes of this command, committed; {note}; not measured in this run)"
     return None, "kernel not in the committed PMC pass"
+
+
+def rocprof_kernel_avg_ms(kernel, D, N):
+    """Average duration of `kernel` in the two committed rocprofv3 --kernel-trace --stats summaries of this command (tools/profile.sh):
+    the headline loop as it runs (calls in flight: the kernel shares the chip with the other calls' kernels) and the same loop with the
+    host fencing behind every step (--one-in-flight: the kernel alone, what the HIP-event pass of this run measures).  NOT measured in
+    this run; None unless the summaries were taken with the counter passes whose source hash matches the tree."""
+    import csv
+    out = {}
+    if not os.path.exists(PMC_FILE):
+        return out
+    with open(PMC_FILE) as f:
+        pmc = json.load(f)
+    if pmc.get("streams_per_gpu") != D or pmc.get("samples_per_stream") != N or not _profile_is_current(pmc)[0]:
+        return out
+    stem = kernel.split("_sym")[0].rstrip("0123456789")         # "k_front_fast47_sym" -> "k_front_fast" (rocprofv3 prints "k_front_fast<47, true>")
+    for key, fn in (("calls_in_flight", STATS_FILE), ("one_call_at_a_time", STATS_ISO_FILE)):
+        if not os.path.exists(fn):
+            continue
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                if row["Name"].startswith(stem + "<"):
+                    out[key] = {"avg_launch_ms": round(float(row["AverageNs"]) / 1e6, 5), "calls": int(row["Calls"]),
+                                "file": os.path.relpath(fn, ROOT)}
+                    break
+    return out
 
 
 def pmc_step_traffic(D, N):

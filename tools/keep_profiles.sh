@@ -4,7 +4,7 @@
 tag=${1:-r06}
 for f in gpurun_out/profiles_$tag/${tag}_*; do
   b=$(basename $f)
-  case $b in ${tag}_sweeps.txt|${tag}_bench_n1.json|${tag}_ab_traffic.txt|${tag}_pipe_*|${tag}_console_example.txt) ;; *) cp $f profiles/$b;; esac
+  case $b in ${tag}_sweeps*|${tag}_mfma_f64_overlap.txt|${tag}_bench_n1.json|${tag}_ab_traffic.txt|${tag}_pipe_*|${tag}_console_example.txt) ;; *) cp $f profiles/$b;; esac
 done
 cp gpurun_out/${tag}_bench_n1_noprof.json profiles/${tag}_bench_n1_noprof.json 2>/dev/null
 python3 -c "

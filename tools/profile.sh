@@ -1,5 +1,6 @@
 #!/bin/bash
-# The round's profiles (run on the GPU box through gpurun: `tools/profile.sh r05`), ONE refresh for the round's kept code: rocprofv3 kernel stats, HBM traffic
+# The round's profiles (run on the GPU box through gpurun: `tools/profile.sh r05`), ONE refresh for the round's kept code: rocprofv3 kernel stats (of the
+# headline loop as it runs, calls in flight, and of the same loop fenced behind every step: the per-kernel figures of bench.py's event pass), HBM traffic
 # (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) and one SQ pass, for the headline batch (64
 # distinct streams), the 12 800-capture scanner batch, the 1 024-stream batch (throughput regime) and stream mode; plus the
 # unprofiled default bench line, the N > 1 step cost on one rank (tools/dist_cost.py) and the clock / LDS micro-benchmark.
@@ -20,6 +21,7 @@ SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 $CAL > $R/gpurun_out/${RT}_bench_n1_noprof.json 2> /dev/null      # (fills the stream cache; also the unprofiled line)
 run() { local name=$1; shift; rocprofv3 "$@" > $R/gpurun_out/$name.log 2>&1 || echo "rocprofv3 $name failed ($?)"; }
 run ${RT}_stats         --kernel-trace --stats -d $R/gpurun_out/${RT}_stats -o ${RT} -- $CAL
+run ${RT}_iso_stats     --kernel-trace --stats -d $R/gpurun_out/${RT}_iso_stats -o ${RT} -- $CAL --one-in-flight   # the same kernels, each with the GPU to itself
 run ${RT}_fetch         --pmc FETCH_SIZE -d $R/gpurun_out/${RT}_fetch -o ${RT} -- $CALC
 run ${RT}_write         --pmc WRITE_SIZE -d $R/gpurun_out/${RT}_write -o ${RT} -- $CALC
 run ${RT}_sq            --pmc $SQ -d $R/gpurun_out/${RT}_sq -o ${RT} -- $CALC
@@ -35,6 +37,7 @@ cd $R
 P="python3 profiles/rocpd_summary.py"
 db() { find gpurun_out/$1 -name '*.db' | head -1; }
 $P stats $(db ${RT}_stats) profiles/${RT}_kernel_stats.csv 3
+$P stats $(db ${RT}_iso_stats) profiles/${RT}_kernel_stats_one_call_at_a_time.csv 3
 $P pmc $(db ${RT}_fetch) $(db ${RT}_write) profiles/${RT}_pmc_traffic.json 64 1020000
 $P sq $(db ${RT}_sq) profiles/${RT}_sq_counters.csv
 $P stats $(db ${RT}_big_stats) profiles/${RT}_streams1024_kernel_stats.csv 3
@@ -65,6 +68,6 @@ python3 tools/dist_cost.py > profiles/${RT}_dist_cost.json 2> gpurun_out/${RT}_d
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/clock_fp64.hip -o /tmp/clock_fp64 && /tmp/clock_fp64 > profiles/${RT}_clock_lds_microbench.txt 2>&1   # (built here: no binary in the tree)
 mkdir -p gpurun_out/profiles_${RT} && cp profiles/${RT}_* gpurun_out/profiles_${RT}/
 # the raw databases stay on the box (gpurun copies back at most 64 MiB); the summaries above are what is kept
-rm -rf gpurun_out/${RT}_stats gpurun_out/${RT}_fetch gpurun_out/${RT}_write gpurun_out/${RT}_sq gpurun_out/${RT}_big_stats gpurun_out/${RT}_big_sq gpurun_out/${RT}_str_stats gpurun_out/${RT}_str_sq gpurun_out/${RT}_scan_stats gpurun_out/${RT}_scan_fetch gpurun_out/${RT}_scan_write gpurun_out/${RT}_scan_sq
+rm -rf gpurun_out/${RT}_stats gpurun_out/${RT}_iso_stats gpurun_out/${RT}_fetch gpurun_out/${RT}_write gpurun_out/${RT}_sq gpurun_out/${RT}_big_stats gpurun_out/${RT}_big_sq gpurun_out/${RT}_str_stats gpurun_out/${RT}_str_sq gpurun_out/${RT}_scan_stats gpurun_out/${RT}_scan_fetch gpurun_out/${RT}_scan_write gpurun_out/${RT}_scan_sq
 ls -la profiles/ | grep ${RT}_
 tail -3 gpurun_out/${RT}_stats.log
