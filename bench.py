@@ -936,6 +936,27 @@ def sub_results(args, torch, gsmcal, dev, ctx, cal, coef, ts, fc, N, stream, mix
             cal.to_host(0)
         t = time_steps(torch, dev, two, K, W, prewarm_s=SUB_PREWARM_S) / K
         sub["config2_two_streams"] = {"streams": 2, "ms_per_call": round(1e3 * t, 4), "Msample_per_s": round(2 * N / t / 1e6, 1)}
+        # ... and with four such calls in flight inside the context (gsmcal_ctx_set_pipeline_depth(4)): the call is a latency chain that
+        # leaves most of the chip idle, so consecutive calls overlap almost entirely (sustained: 10 x K calls between the fences)
+        try:
+            ref2 = cal.table(0).numpy()[:2].copy()
+            kk2 = [0]
+
+            def two_in_flight():
+                b_ = kk2[0] % 4
+                kk2[0] += 1
+                cal.launch(b_, 2)
+                cal.to_host(b_)
+            ctx.set_pipeline_depth(4)
+            t4 = time_steps(torch, dev, two_in_flight, 10 * K, W, prewarm_s=SUB_PREWARM_S) / (10 * K)
+            ctx.set_pipeline_depth(1)
+            ctx.sync()
+            same2 = all(bool(np.array_equal(cal.table(b_).numpy()[:2], ref2, equal_nan=True)) for b_ in range(4))
+            sub["config2_two_streams"].update({"ms_per_call_pipeline_depth4": round(1e3 * t4, 4), "Msample_per_s_pipeline_depth4": round(2 * N / t4 / 1e6, 1),
+                                               "tables_identical_across_output_sets": same2})
+        except Exception as e:  # noqa: BLE001
+            ctx.set_pipeline_depth(1)
+            sub["config2_two_streams"]["pipeline_depth4_error"] = repr(e)
         cal.launch(0)
         torch.cuda.synchronize(dev)
     # the same streams with the corrected stream written (the API's real output, 18 B/sample)
