@@ -694,6 +694,73 @@ def test_pipelined_calls_with_the_corrected_stream(g, setup):
             cx.close()
 
 
+def test_unlike_calls_in_flight(g, setup):
+    """Calls in flight need not be alike: batch sizes 5 / 2 / 7 / 3, a different carrier frequency (a changed input: the call joins
+    the ones in flight before it uploads), a different filter, the depth changed in mid-sequence, a 130-stream call (two lanes: not
+    pipelined, runs joined) and scanner sweeps between them -- every call into its own output set, every output bit for bit what the
+    same call gives alone on a fresh context."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = g.synth
+    streams = np.stack([s.make_stream(dongle=40 + d, num_frames=61)[0] for d in range(8)])
+    n = streams.shape[1] // 2
+    caps = np.stack([s.make_stream(dongle=9300, arfcn=i, num_frames=40, bcch=i % 3 != 2)[0] for i in range(12)])
+    coef30 = s.fir1(30, 200e3 / s.FS)
+    coef_b = s.fir1(46, 180e3 / s.FS)                          # another 47-tap filter: a changed input
+    big = np.stack([streams[i % 8] for i in range(130)])
+    # (kind, rows, coef, carrier frequency, depth to set before the call)
+    plan = [("cal", slice(0, 5), setup["coef"], FC, 4), ("cal", slice(5, 7), setup["coef"], FC, None), ("scan", slice(0, 12), coef30, None, None),
+            ("cal", slice(1, 8), setup["coef"], FC, None), ("cal", slice(0, 3), setup["coef"], 1.8e9, None), ("cal", slice(2, 7), coef_b, FC, None),
+            ("cal", slice(0, 5), setup["coef"], FC, 2), ("big", None, setup["coef"], FC, None), ("scan", slice(3, 9), coef30, None, 3),
+            ("cal", slice(4, 8), setup["coef"], FC, None), ("cal", slice(0, 5), setup["coef"], FC, None)]
+    refs = []
+    for kind, rows, coef, fc, _ in plan:                       # every call alone, default context
+        if kind == "scan":
+            r = g.fcch_scan_batch(caps[rows], coef)
+            refs.append(np.stack([r["snr"], r["num_hit"]], axis=1))
+        else:
+            refs.append(g.calibrate_batch(big if kind == "big" else streams[rows], coef, setup["ts"], fc))
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        cx = g.Context(0, stream=st.cuda_stream)
+        try:
+            keep, outs = [], []
+            for kind, rows, coef, fc, depth in plan:
+                if depth:
+                    cx.set_pipeline_depth(depth)
+                if kind == "scan":
+                    r_t = torch.from_numpy(np.ascontiguousarray(caps[rows])).to(dev)
+                    o_t = torch.zeros((r_t.shape[0], 2), dtype=torch.float64, device=dev)
+                    st.synchronize()
+                    g.fcch_scan_batch_dev(r_t.data_ptr(), r_t.shape[0], caps.shape[1] // 2, coef, o_t.data_ptr(), ctx=cx)
+                    outs.append((o_t,))
+                else:
+                    raw = big if kind == "big" else np.ascontiguousarray(streams[rows])
+                    r_t = torch.from_numpy(raw).to(dev)
+                    d = raw.shape[0]
+                    tab = torch.zeros((d, g.TABLE_COLS), dtype=torch.float64, device=dev)
+                    pos = torch.zeros((d, 2, g.MAX_POS_ROWS), dtype=torch.float64, device=dev)
+                    rl = torch.zeros((d,), dtype=torch.int64, device=dev)
+                    st.synchronize()
+                    g.calibrate_batch_dev(r_t.data_ptr(), d, n, coef, setup["ts"], fc, tab.data_ptr(), pos.data_ptr(), None, rl.data_ptr(), ctx=cx)
+                    outs.append((tab, pos, rl))
+                keep.append(r_t)
+            assert cx.pipeline_depth() == 3
+            cx.sync()
+            for k, ((kind, rows, coef, fc, _), ref, out) in enumerate(zip(plan, refs, outs)):
+                if kind == "scan":
+                    assert np.array_equal(out[0].cpu().numpy(), ref, equal_nan=True), k
+                    continue
+                tab, pos, rl = (o.cpu().numpy() for o in out)
+                assert np.array_equal(tab, ref["table"], equal_nan=True), (k, kind)
+                assert np.array_equal(rl, ref["r_len"]), k
+                for i in range(tab.shape[0]):
+                    if tab[i, 8] != -1.0:
+                        assert np.array_equal(pos[i, :, :int(tab[i, 7])].T, ref["pos_info"][i]), (k, i)
+        finally:
+            cx.close()
+
+
 def test_1024_stream_batch_on_staggered_lanes(g, setup):
     """1 024 streams in one call: four lanes of 256 whose front kernels follow one another (the default from 256 streams per lane
     on) -- every copy of a stream gets the row it gets in a batch of its own."""
