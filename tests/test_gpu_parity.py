@@ -725,9 +725,14 @@ def test_unlike_calls_in_flight(g, setup):
         cx = g.Context(0, stream=st.cuda_stream)
         try:
             keep, outs = [], []
-            for kind, rows, coef, fc, depth in plan:
+            scratch = torch.zeros((8, g.TABLE_COLS), dtype=torch.float64, device=dev)
+            for k_call, (kind, rows, coef, fc, depth) in enumerate(plan):
                 if depth:
                     cx.set_pipeline_depth(depth)
+                if k_call in (3, 9):                           # refused calls between the others leave the calls in flight alone
+                    for bad_ptr, bad_d, bad_n in ((scratch.data_ptr(), 0, n), (scratch.data_ptr(), 4, 0), (0, 4, n)):
+                        with pytest.raises(g.GsmcalError):
+                            g.calibrate_batch_dev(bad_ptr, bad_d, bad_n, setup["coef"], setup["ts"], FC, scratch.data_ptr(), ctx=cx)
                 if kind == "scan":
                     r_t = torch.from_numpy(np.ascontiguousarray(caps[rows])).to(dev)
                     o_t = torch.zeros((r_t.shape[0], 2), dtype=torch.float64, device=dev)
