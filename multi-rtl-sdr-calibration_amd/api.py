@@ -97,10 +97,15 @@ class Context:
         except Exception:  # noqa: BLE001
             pass
 
+    _E_NAMES = {-1: "GSMCAL_E_ARG (an argument is null, zero or out of its documented range: include/gsmcal.h)", -2: "GSMCAL_E_HIP",
+                -3: "GSMCAL_E_NO_DEVICE", -4: "GSMCAL_E_CAPACITY (an output buffer's capacity argument is too small)",
+                -5: "GSMCAL_E_INDEX (MATLAB would raise 'index exceeds matrix dimensions')", -6: "GSMCAL_E_UNSUPPORTED"}
+
     def check(self, rc, what):
         if rc < 0:
             msg = self.lib.gsmcal_last_error(self.h)
-            raise GsmcalError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+            text = msg.decode() if msg else ""
+            raise GsmcalError(f"{what} failed with {rc} = {self._E_NAMES.get(rc, '?')}" + (f": {text}" if text else ""))
         return rc
 
     def sync(self):
