@@ -134,8 +134,8 @@ const char* gsmcal_version(void);
  *     gsmcal_allgather_table[_async] right behind a pipelined call is enqueued behind THAT call (the gathered table completes where
  *     the call's own outputs do).  gsmcal_last_batch_details describes the most recent call.
  * Results are identical at every depth (same kernels, same order per call).  Returns GSMCAL_E_ARG for depth < 1 or > 8.
- * (GSMCAL_PIPE_STAGES=2|3 selects the staged forms of the first design -- a call cut into front end | fine search | fused tail on
- * stage streams -- which measured no gain: INTEGRATION.md, profiles/NOTES_r06.md.) */
+ * (The staged forms of the first design -- a call cut into front end | fine search | fused tail on stage streams -- measured no gain
+ * and are not in the library: profiles/experiments_r06/staged_pipeline_and_side_fused.patch, profiles/NOTES_r06.md.) */
 int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* ctx, int depth);
 int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* ctx);
 /* Diagnostics of the batch path's fused tail (one launch for everything behind the fine search's chunk sweep: its workgroups

@@ -107,8 +107,6 @@ int gsmcal_ctx_create_on_stream(int device_id, void* hip_stream, gsmcal_ctx** ou
     if (fg && atoi(fg) != 0) c->front_generic = true;
     if (const char* e2 = getenv("GSMCAL_FUSED_POLL_S")) { if (atof(e2) > 0.0) c->fused_poll_s = atof(e2); }
     if (const char* e2 = getenv("GSMCAL_TEST_FUSED_STALL")) c->test_stall = atoi(e2);
-    if (const char* e2 = getenv("GSMCAL_PIPE_STAGES")) c->pipe_stages = atoi(e2) >= 3 ? 3 : (atoi(e2) <= 1 ? 1 : 2);
-    if (const char* e2 = getenv("GSMCAL_PIPE_SIDE_FUSED")) c->pipe_side_fused = atoi(e2) != 0;
     const char* ge = getenv("GSMCAL_GRAPH");
     if (ge && atoi(ge) == 0) c->use_graph = false;
     if (ge && atoi(ge) == 2) c->graph_always = true;
@@ -157,14 +155,10 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
         DevBuf* lb[] = {&L.state, &L.dec, &L.win, &L.peaks, &L.snrbuf, &L.x0, &L.chunkrec, &L.openlist, &L.cert, &L.partial, &L.tailctr, &L.xch, &L.xepoch};
         for (DevBuf* b : lb)
             if (b->p) (void)hipFree(b->p);
-        for (int k = 0; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
-            if (c->pipe_handover[i][k]) (void)hipEventDestroy(c->pipe_handover[i][k]);
+        if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
         if (c->side_in[i]) (void)hipEventDestroy(c->side_in[i]);
-        if (c->side_tail[i]) (void)hipEventDestroy(c->side_tail[i]);
         if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
     }
-    for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
-        if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (hipEvent_t e : c->ag_chain)
         if (e) (void)hipEventDestroy(e);
@@ -730,12 +724,12 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
         c->err = "capture shorter than 23 frames after decimation (FCCH_coarse_position.m:25 would index past the end)";
         return GSMCAL_E_INDEX;
     }
-    // Calls in flight (gsmcal_ctx_set_pipeline_depth > 1, the side-by-side form): a single-stage scanner batch (up to 1 199 captures)
+    // Calls in flight (gsmcal_ctx_set_pipeline_depth > 1): a single-stage scanner batch (up to 1 199 captures)
     // runs on internal stream i mod depth in workspace i mod depth, so the detector of call i -- one resident round of latency-bound
     // workgroups -- sits underneath the bandwidth-bound front kernel of call i+1 (multi_rtl_sdr_gsm_FCCH_scanner.m:132-135,163-186
     // over consecutive sweeps).  Same semantics as for calibration calls: outputs complete at call i + depth / gsmcal_sync / any other
     // entry point.
-    bool pipelined = c->pipe_depth > 1 && c->pipe_stages == 1 && !c->prof && c->stream != nullptr && plan_lanes(c, d, false) == 1;
+    bool pipelined = c->pipe_depth > 1 && !c->prof && c->stream != nullptr && plan_lanes(c, d, false) == 1;
     if (pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); pipelined = false; }
@@ -752,10 +746,9 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     if (pipelined) {
         RET_IF(pipe_prepare(c));
         const int slot = (int)(c->pipe_calls % (unsigned long)c->pipe_depth);
-        const int last_ev = gsmcal_ctx::PIPE_MAX_STAGES - 1;
         Lane& L = c->pipe[slot];
         if (c->pipe_pending[slot]) {
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[slot][last_ev], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_done[slot], 0));
             c->pipe_pending[slot] = false;
         }
         HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
@@ -771,10 +764,9 @@ int gsmcal_fcch_scan_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             acc.snr_numhit = d_snr_numhit; acc.positions = d_positions; acc.pos_snr = d_pos_snr; acc.counts = d_counts;
             rc = coarse(c, d, (const cplx*)L.dec.p, nd, nd, dec_ratio, 0, true, n, decim, &acc, true);
         }
-        if (hipEventRecord(c->pipe_handover[slot][last_ev], L.stream) != hipSuccess) { c->err = "hipEventRecord (pipeline)"; rc = GSMCAL_E_HIP; }
+        if (hipEventRecord(c->pipe_done[slot], L.stream) != hipSuccess) { c->err = "hipEventRecord (calls in flight)"; rc = GSMCAL_E_HIP; }
         c->pipe_pending[slot] = true;
         c->pipe_last_slot = slot;
-        c->pipe_last_stages = 1;
         ++c->pipe_calls;
         c->detail_lane = &L;
         c->cur = &c->lanes[0];
@@ -887,27 +879,26 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     const long nd = (n + decim - 1) / decim;
     int H = hits_capacity(nd, dec_ratio) + 1;
     if (H > MAXH) return GSMCAL_E_CAPACITY;
-    // Pipelined call (gsmcal_ctx_set_pipeline_depth > 1): table-mode calls that run on one lane.  Anything that would touch
-    // what the calls in flight still read (new taps / training sequence / carrier frequencies, a workspace that must grow, the
-    // twiddle table) joins them into the context's stream first.
-    // (with r_correct only the side-by-side form: the staged forms put the tail on a stage stream the stream kernel would hold up)
-    const bool want_pipe = c->pipe_depth > 1 && (!d_r_correct || c->pipe_stages == 1) && c->stream != nullptr && plan_lanes(c, d) == 1;
+    // Calls in flight (gsmcal_ctx_set_pipeline_depth > 1): calls that run on one lane.  Anything that would touch what the calls in
+    // flight still read (new taps / training sequence / carrier frequencies, a workspace that must grow, the twiddle table) joins
+    // them into the context's stream first.
+    const bool want_pipe = c->pipe_depth > 1 && c->stream != nullptr && plan_lanes(c, d) == 1;
     bool pipelined = want_pipe && !c->prof;
     if (pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); pipelined = false; }
     }
     // (events on every dispatch -- gsmcal_profile_enable -- or the caller's own stream capture: one call at a time, but with the
-    // kernels the pipelined calls run, so that a per-kernel profile of a depth-4 context describes what the depth-4 loop launches)
-    const bool same_kernels_unpipelined = want_pipe && !pipelined && c->pipe_stages == 1 && !c->pipe_side_fused;
+    // kernels the calls in flight run, so that a per-kernel profile of a depth-4 context describes what the depth-4 loop launches)
+    const bool same_kernels_unpipelined = want_pipe && !pipelined;
     const bool same_inputs = (int)c->h_coef.size() == ntaps && memcmp(c->h_coef.data(), coef, (size_t)ntaps * sizeof(double)) == 0 &&
                              c->h_ts.size() == (size_t)2 * len_ts && memcmp(c->h_ts.data(), sch_ts, (size_t)2 * len_ts * sizeof(double)) == 0 &&
                              (int)c->h_cf.size() == d && memcmp(c->h_cf.data(), carrier_freq, (size_t)d * sizeof(double)) == 0 &&
                              c->tw_n == g.nfft && c->head_epoch == c->coef_epoch;
     if (!pipelined || !same_inputs) RET_IF(pipe_join(c));
     c->cur = &c->lanes[0];
-    c->xlane = nullptr; c->detail_lane = nullptr; c->split_stream = nullptr;      // (also what an earlier call that failed half-way may have left set)
-    c->tail_wait = nullptr; c->tail_record = nullptr; c->cf_lane = nullptr; c->no_fuse_now = same_kernels_unpipelined;
+    c->detail_lane = nullptr; c->cf_lane = nullptr;       // (also what an earlier call that failed half-way may have left set)
+    c->no_fuse_now = same_kernels_unpipelined;
     c->call_raw_bytes = (size_t)d * 2 * (size_t)n;
     c->call_raw_fresh = (const void*)d_raw != c->last_raw;
     c->last_raw = d_raw;
@@ -917,45 +908,26 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
     RET_IF(ensure_head(c, decim));
     RET_IF(ensure_twiddles(c, g.nfft));
     if (pipelined) {
-        // slot = workspace of this call; the context's stream first waits for the call that used it `depth` calls ago (that call's
-        // outputs are complete in the context's stream order from here on)
+        // slot = workspace and stream of this call; the context's stream first waits for the call that used it `depth` calls ago
+        // (that call's outputs are complete in the context's stream order from here on), then the slot's stream takes the call behind
+        // whatever the context's stream holds now: front end + coarse detector (:107,110,117), fine search (:118), four-launch tail
         RET_IF(pipe_prepare(c));
         const int slot = (int)(c->pipe_calls % (unsigned long)c->pipe_depth);
-        const int nst = c->pipe_stages;
-        const int last_ev = gsmcal_ctx::PIPE_MAX_STAGES - 1;
         Lane& L = c->pipe[slot];
         if (c->pipe_pending[slot]) {
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[slot][last_ev], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_done[slot], 0));
             c->pipe_pending[slot] = false;
         }
         c->cur = &L;
         c->n_lanes_used = 1;
         L.lo = 0; L.n = d;
-        if (nst == 1) {
-            // whole calls side by side: this call on the slot's own stream behind whatever the context's stream holds now; its fused
-            // tail behind the previous call's (one in flight)
-            HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->side_stream[slot], c->side_in[slot], 0));
-            L.stream = c->side_stream[slot];
-            if (c->pipe_side_fused) {                      // (experiment switch of tools/pipe_ab.sh: fused tails, chained one behind the other)
-                c->tail_wait = c->side_last_tail >= 0 && c->side_last_tail != slot ? c->side_tail[c->side_last_tail] : nullptr;
-                c->tail_record = c->side_tail[slot];
-            } else {
-                c->no_fuse_now = true;
-            }
-        } else {
-            L.stream = c->stream;                                        // ---- stage 0: front end + coarse detector (:107,110,117)
-        }
+        HIPCHK(c, hipEventRecord(c->side_in[slot], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream[slot], c->side_in[slot], 0));
+        L.stream = c->side_stream[slot];
+        c->no_fuse_now = true;
         RET_IF(ensure(c, L.dec, (size_t)d * nd * sizeof(cplx)));
         RET_IF(front_fused(c, d_raw, d, n, (const double*)c->coef.p, ntaps, decim, (cplx*)L.dec.p, nd));
         RET_IF(coarse(c, d, (const cplx*)L.dec.p, nd, nd, dec_ratio, ov, true, n, decim));
-        if (nst > 1) {
-            HIPCHK(c, hipEventRecord(c->pipe_handover[slot][0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->pipe_stream[1], c->pipe_handover[slot][0], 0));
-            L.stream = c->pipe_stream[1];                                // ---- stage 1: fine search (:118) [+ stage 2: everything behind the chunk sweep]
-        }
-        if (nst >= 3) { c->split_stream = c->pipe_stream[2]; c->split_event = c->pipe_handover[slot][1]; }
-        c->xlane = &c->lanes[0];
         Source src{SRC_RAW, d_raw, 2 * n, nullptr, 0, (const double*)c->coef.p, ntaps};
         c->cf_lane = (const double*)c->cf.p;
         ChainOut co{d_table, d_pos_info, d_r_len, false};
@@ -965,16 +937,11 @@ int gsmcal_calibrate_batch_dev(gsmcal_ctx* c, const uint8_t* d_raw, int d, long 
             if (rc >= 0) rc = run_post(c, d, src, 3, g, H, true, co.table, co.pos_info_out, co.r_len_out);
         }
         if (rc >= 0 && d_r_correct) rc = launch_r_correct(c, L, src, d_raw, d, n, ntaps, d_r_correct);
-        const hipStream_t out_stream = L.stream;                         // (stage 1's stream, or stage 2's when the call hopped)
-        c->cf_lane = nullptr; c->xlane = nullptr; c->split_stream = nullptr; c->no_fuse_now = false;
-        if (nst == 1 && rc >= 0 && co.fused) c->side_last_tail = slot;
-        c->tail_wait = nullptr; c->tail_record = nullptr;
-        if (hipEventRecord(c->pipe_handover[slot][last_ev], out_stream) != hipSuccess) { c->err = "hipEventRecord (pipeline)"; rc = GSMCAL_E_HIP; }
+        c->cf_lane = nullptr; c->no_fuse_now = false;
+        if (hipEventRecord(c->pipe_done[slot], L.stream) != hipSuccess) { c->err = "hipEventRecord (calls in flight)"; rc = GSMCAL_E_HIP; }
         c->pipe_pending[slot] = true;
         c->pipe_last_slot = slot;
-        c->pipe_last_stages = nst == 1 ? 1 : (out_stream == c->pipe_stream[2] ? 3 : 2);
         ++c->pipe_calls;
-        if (rc >= 0 && co.fused) record_fused_call(c, d_raw, d, n, ntaps, len_ts, d_table, d_pos_info, d_r_correct, d_r_len);
         c->detail_lane = &L;
         c->cur = &c->lanes[0];
         c->last_S = d;

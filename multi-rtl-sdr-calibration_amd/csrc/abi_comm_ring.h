@@ -222,7 +222,7 @@ int gsmcal_allgather_table(gsmcal_ctx* c, gsmcal_comm* g, const double* d_local,
         if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToDevice));
         HIPCHK(c, hipEventRecord(ev, st));
         ++c->ag_chain_n;
-        HIPCHK(c, hipEventRecord(c->pipe_handover[c->pipe_last_slot][gsmcal_ctx::PIPE_MAX_STAGES - 1], st));   // the call's completion now includes its collective
+        HIPCHK(c, hipEventRecord(c->pipe_done[c->pipe_last_slot], st));   // the call's completion now includes its collective
     }
     return 0;
 }

@@ -105,40 +105,28 @@ struct gsmcal_ctx {
     bool fuse_post = true;          // GSMCAL_FUSE_POST=0: k_fine_verify, k_burst_tone<1>, k_window_sch, k_burst_tone<0> as four launches
     bool front_generic = false;     // GSMCAL_FRONT_GENERIC=1: the any-geometry front kernel also for the 47/31-tap production geometry
     bool capturing = false;
-    // ---- pipelined batch calls (gsmcal_ctx_set_pipeline_depth; gsm_sync_demod.m:107-124 over consecutive batches) ----
-    // Up to `pipe_depth` consecutive single-lane calibration calls in flight, each in a workspace of its own (pipe[slot]).
-    // pipe_stages = 1 (default): WHOLE calls side by side, call i on internal stream i mod depth behind an event on the context's
-    // stream, every call with the FOUR-LAUNCH tail -- its kernels wait for nobody and hold no slot while idle, so the kernels of
-    // up to four calls interleave workgroup by workgroup as slots free up: 64 streams 0.177 -> 0.148 / 0.138 ms per call at depth
-    // 3 / 4 (more streams than the device's four hardware queues gain nothing).  pipe_stages = 2 / 3 (kept for the record,
-    // NOTES_r06): a call cut into stages (front end + coarse detector | fine search | fused tail) on stage streams chained by
-    // events, all fused tails on one stream sharing lane 0's exchange block -- no gain: the fused tail and the certificate
-    // each fill every CU's registers and LDS, nothing of the next call fits beside them.
-    static constexpr int PIPE_MAX_DEPTH = 8, PIPE_MAX_STAGES = 3;
+    // ---- calls in flight (gsmcal_ctx_set_pipeline_depth; gsm_sync_demod.m:107-124 over consecutive batches) ----
+    // Up to `pipe_depth` consecutive single-lane batch calls in flight, each in a workspace of its own (pipe[slot]): WHOLE calls side
+    // by side, call i on internal stream i mod depth behind an event on the context's stream, every calibration call with the
+    // FOUR-LAUNCH tail -- its kernels wait for nobody and hold no slot while idle, so the kernels of up to four calls interleave
+    // workgroup by workgroup as slots free up: 64 streams 0.177 -> 0.148 / 0.138 ms per call at depth 3 / 4 (more streams than the
+    // device's four hardware queues gain nothing).  The forms measured and dropped -- a call cut into stages on stage streams with
+    // the fused tail kept (no gain: the fused tail and the certificate each fill every CU's registers and LDS), fused tails chained
+    // or mixed in among side-by-side calls (slower) -- are profiles/experiments_r06/staged_pipeline_and_side_fused.patch, NOTES_r06.
+    static constexpr int PIPE_MAX_DEPTH = 8;
     int pipe_depth = 1;             // 1: a call is complete in stream order when it returns (the semantics of every earlier release)
-    int pipe_stages = 1;            // GSMCAL_PIPE_STAGES: 1 = whole calls side by side (four-launch tails), 2 = front | tail, 3 = front | fine search | fused tail
-    bool pipe_side_fused = false;   // GSMCAL_PIPE_SIDE_FUSED=1 (experiment): side-by-side calls keep the fused tail, chained one behind the other
     Lane pipe[PIPE_MAX_DEPTH];
-    hipStream_t pipe_stream[PIPE_MAX_STAGES] = {nullptr, nullptr, nullptr};   // [0] unused: stage 0 runs on the context's stream
-    hipEvent_t pipe_handover[PIPE_MAX_DEPTH][PIPE_MAX_STAGES] = {};          // [slot][k]: end of stage k of the slot's call
-    bool pipe_pending[PIPE_MAX_DEPTH] = {};                                   // the slot's call has not been joined into the context's stream yet
+    hipStream_t side_stream[PIPE_MAX_DEPTH] = {};     // call i runs on side_stream[i mod depth]
+    hipEvent_t side_in[PIPE_MAX_DEPTH] = {};          // the context's stream at the moment the slot's call was enqueued
+    hipEvent_t pipe_done[PIPE_MAX_DEPTH] = {};        // end of the slot's call (plus a collective enqueued right behind it)
+    bool pipe_pending[PIPE_MAX_DEPTH] = {};           // the slot's call has not been joined into the context's stream yet
     unsigned long pipe_calls = 0;
-    int pipe_last_slot = -1;        // slot of the most recent pipelined call, -1: none since the last join
-    int pipe_last_stages = 0;
-    Lane* xlane = nullptr;          // != nullptr: the lane whose exchange block / launch counters the fused tail uses instead of cur's
-    Lane* detail_lane = nullptr;    // the workspace gsmcal_last_batch_details / _snr read (pipelined call), nullptr: lanes[]
-    hipStream_t split_stream = nullptr;   // run_fine(): behind the chunk sweep the call hops to this stream (third pipeline stage)
-    hipEvent_t split_event = nullptr;
-    // side-by-side calls: call i on internal stream i mod depth.  (pipe_side_fused: the fused tails chained, tail i+1 behind tail i --
-    // at most one in flight, as the gate demands of separate contexts; measured slower than the four-launch tails, NOTES_r06)
-    hipStream_t side_stream[PIPE_MAX_DEPTH] = {};
-    bool no_fuse_now = false;             // the call being enqueued takes the four-launch tail whatever the batch size (side-by-side calls)
+    int pipe_last_slot = -1;        // slot of the most recent call in flight, -1: none since the last join
+    Lane* detail_lane = nullptr;    // the workspace gsmcal_last_batch_details / _snr read (call in flight), nullptr: lanes[]
+    bool no_fuse_now = false;             // the call being enqueued takes the four-launch tail whatever the batch size (calls in flight)
                                           // ... and the SNR table of the moving search only (the hop walk on its own spectra): with calls in
                                           // flight the full table's 27 MB and its screening pass cost more than the walk's latency saves
                                           // (four deep, 100 steps: 0.1315 -> 0.1287 ms per call; one call at a time it is the other way round)
-    hipEvent_t side_in[PIPE_MAX_DEPTH] = {}, side_tail[PIPE_MAX_DEPTH] = {};
-    hipEvent_t tail_wait = nullptr, tail_record = nullptr;   // run_fine(): events around the fused tail's launch
-    int side_last_tail = -1;              // slot whose fused tail was enqueued last (-1: none pending)
     struct OccEntry { int variant; size_t lds; int blocks; };
     std::vector<OccEntry> occ_cache;  // post_chain_blocks_per_cu()
     int post_slots_cap = 0;           // GSMCAL_POST_SLOTS: upper bound on the fused tail's workgroups per CU (0: the occupancy calculator's figure)
@@ -584,12 +572,7 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                (ChunkRec*)c->cur->chunkrec.p, H, (const int*)open_items, (const int*)n_open);
         const size_t vlds = ((size_t)g.fine_wlen * sizeof(cplx) + FV_MAX_ITEMS * (sizeof(int) + sizeof(cplx)) + 15) & ~(size_t)15;
         sa_fine.NB = 1;
-        if (c->split_stream) {      // pipelined call in three stages: everything behind the chunk sweep runs on the third stage's stream
-            HIPCHK(c, hipEventRecord(c->split_event, c->cur->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->split_stream, c->split_event, 0));
-            c->cur->stream = c->split_stream;
-        }
-        Lane* const X = c->xlane ? c->xlane : c->cur;   // (pipelined calls: one exchange block and one set of launch counters for all slots)
+        Lane* const X = c->cur;
         if (chain) {
             // ---- the fused tail of the chain: verify -> bursts -> SCH windows -> post-SCH bursts in one launch ----
             const int wl_sch = g.sch_nshift - 1 + len_ts;
@@ -654,7 +637,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                 pa.timed_out = c->fused_done ? c->fused_done + gsmcal_ctx::FUSED_MAX_STREAMS : nullptr;
                 pa.poll_ticks = (unsigned long long)(c->fused_poll_s * 1e8);
                 pa.test_stall = c->recovering ? 0 : c->test_stall;
-                if (c->tail_wait) HIPCHK(c, hipStreamWaitEvent(c->cur->stream, c->tail_wait, 0));
                 if (ref_geom) LAUNCH(c, (k_post_chain_r<8, 512, 47>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
                 else LAUNCH(c, (k_post_chain_r<0, 0, 0>), dim3(H, S), dim3(PC_THREADS), lds, st, pa, (unsigned long long*)X->xch.p, (unsigned*)X->xepoch.p);
                 {
@@ -665,7 +647,6 @@ int run_fine(gsmcal_ctx* c, int S, const Source& src, int lvl, const Geom& g, in
                         return GSMCAL_E_HIP;
                     }
                 }
-                if (c->tail_record) HIPCHK(c, hipEventRecord(c->tail_record, c->cur->stream));
                 return 0;
             }
         }
@@ -1035,50 +1016,36 @@ int join_lanes(gsmcal_ctx* c, int nl) {
     return 0;
 }
 
-// ---- pipelined calls: streams, events, joining --------------------------------------------------------------------------
+// ---- calls in flight: streams, events, joining ---------------------------------------------------------------------------
 int pipe_prepare(gsmcal_ctx* c) {
-    for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)   // (default priority: the later stages at the highest priority measured no better, NOTES_r06)
-        if (!c->pipe_stream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
     for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) {
-        if (!c->side_stream[s]) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[s], hipStreamNonBlocking));
-        for (hipEvent_t* e : {&c->side_in[s], &c->side_tail[s]})
-            if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
-                (void)hipGetLastError();
-                HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-            }
+        if (!c->side_stream[s]) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[s], hipStreamNonBlocking));   // (default priority: a higher one for some slots measured no better, NOTES_r06)
+        if (!c->side_in[s] && hipEventCreateWithFlags(&c->side_in[s], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(c, hipEventCreateWithFlags(&c->side_in[s], hipEventDisableTiming));
+        }
+        // the end of a call also orders the table row stored in host memory -- a plain event
+        if (!c->pipe_done[s]) HIPCHK(c, hipEventCreateWithFlags(&c->pipe_done[s], hipEventDisableTiming));
     }
-    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
-        for (int k = 0; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
-            if (!c->pipe_handover[s][k]) {
-                // hand-overs between stages: device-scope release (see get_event()); the end of the last stage also orders
-                // the table row stored in host memory -- a plain event
-                const unsigned fl = k + 1 < gsmcal_ctx::PIPE_MAX_STAGES ? (hipEventDisableTiming | hipEventReleaseToDevice) : hipEventDisableTiming;
-                if (hipEventCreateWithFlags(&c->pipe_handover[s][k], fl) != hipSuccess) {
-                    (void)hipGetLastError();
-                    HIPCHK(c, hipEventCreateWithFlags(&c->pipe_handover[s][k], hipEventDisableTiming));
-                }
-            }
     return 0;
 }
 
-// The stream the outputs of the most recent batch call are ordered on: the last stage's stream while a pipelined call is
-// pending, else the context's stream.
+// The stream the outputs of the most recent batch call are ordered on: the slot's stream while that call is in flight, else the
+// context's stream.
 hipStream_t pipe_out_stream(gsmcal_ctx* c) {
     if (c->pipe_last_slot < 0 || !c->pipe_pending[c->pipe_last_slot]) return c->stream;
-    if (c->pipe_last_stages == 1) return c->side_stream[c->pipe_last_slot];
-    return c->pipe_stream[c->pipe_last_stages - 1];
+    return c->side_stream[c->pipe_last_slot];
 }
 
-// The context's stream waits for every pipelined call still in flight (GPU-side waits, the host does not block): from here on
-// the context behaves as at depth 1.  Every entry point but the pipelined batch call itself starts with this.
+// The context's stream waits for every call still in flight (GPU-side waits, the host does not block): from here on the context
+// behaves as at depth 1.  Every entry point but the batch calls that go in flight themselves starts with this.
 int pipe_join(gsmcal_ctx* c) {
     for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
         if (c->pipe_pending[s]) {
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_handover[s][gsmcal_ctx::PIPE_MAX_STAGES - 1], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_done[s], 0));
             c->pipe_pending[s] = false;
         }
     c->pipe_last_slot = -1;
-    c->side_last_tail = -1;
     return 0;
 }
 
@@ -1086,12 +1053,9 @@ int pipe_join(gsmcal_ctx* c) {
 int pipe_drain(gsmcal_ctx* c) {
     bool any = false;
     for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) any = any || c->pipe_pending[s];
-    if (any) {
-        for (int k = 1; k < gsmcal_ctx::PIPE_MAX_STAGES; ++k)
-            if (c->pipe_stream[k]) HIPCHK(c, hipStreamSynchronize(c->pipe_stream[k]));
+    if (any)
         for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
             if (c->side_stream[s]) HIPCHK(c, hipStreamSynchronize(c->side_stream[s]));
-    }
     return pipe_join(c);
 }
 

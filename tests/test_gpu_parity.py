@@ -962,20 +962,19 @@ def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setu
     orcs = parity.pool_map(parity.oracle_job, [(raw[i], setup["coef"], setup["ts"], FC) for i in range(64)])
     for i in range(64):
         parity.compare_stream(orcs[i], out["table"][i], det, i, out["pos_info"][i])
-    # ... and the same batch through PIPELINED calls (gsmcal_ctx_set_pipeline_depth): eight consecutive
-    # gsmcal_calibrate_batch_dev calls in flight two to eight deep -- whole calls side by side with the four-launch tail (stages "1",
-    # the default) and the staged forms with the fused tail ("2", "3") -- each into its own output set: every table, pos_info and
-    # r_len bit for bit what the one-call-at-a-time path returned, and last_batch_details describes the last call
+    # ... and the same batch through CALLS IN FLIGHT (gsmcal_ctx_set_pipeline_depth): eight consecutive
+    # gsmcal_calibrate_batch_dev calls two to eight deep -- whole calls side by side, each with the four-launch tail -- each into its
+    # own output set: every table, pos_info and r_len bit for bit what the one-call-at-a-time path (fused tail) returned, and
+    # last_batch_details describes the last call
     import torch
     dev = torch.device("cuda", 0)
     raw_t = torch.from_numpy(raw).to(dev)
     n = raw.shape[1] // 2
-    for stages, depth in (("1", 2), ("1", 4), ("1", 3), ("1", 8), ("2", 2), ("3", 3), ("3", 2), ("2", 4)):
-        os.environ["GSMCAL_PIPE_STAGES"] = stages
+    for depth in (2, 4, 3, 8, 5):
         st = torch.cuda.Stream(device=dev)
-        try:
-            with torch.cuda.stream(st):
-                cx = g.Context(0, stream=st.cuda_stream)
+        with torch.cuda.stream(st):
+            cx = g.Context(0, stream=st.cuda_stream)
+            try:
                 cx.set_pipeline_depth(depth)
                 assert cx.pipeline_depth() == depth
                 tabs = [torch.zeros((64, g.TABLE_COLS), dtype=torch.float64, device=dev) for _ in range(8)]
@@ -987,29 +986,29 @@ def test_baseline_batch_64_distinct_streams_every_row_against_the_oracle(g, setu
                 det_p = g.last_batch_details(64, ctx=cx)           # (joins the calls in flight)
                 cx.sync()
                 for k in range(8):
-                    assert np.array_equal(tabs[k].cpu().numpy(), out["table"], equal_nan=True), (stages, depth, k)
+                    assert np.array_equal(tabs[k].cpu().numpy(), out["table"], equal_nan=True), (depth, k)
                     pk = poss[k].cpu().numpy()
                     for i in range(64):
                         rows = int(out["table"][i, 7])
-                        assert np.array_equal(pk[i, :, :rows].T, out["pos_info"][i]), (stages, depth, k, i)
+                        assert np.array_equal(pk[i, :, :rows].T, out["pos_info"][i]), (depth, k, i)
                     assert np.array_equal(rls[k].cpu().numpy(), rls[0].cpu().numpy())
                 for key in det:
-                    if key == "coarse_snr" and stages == "1":
+                    if key == "coarse_snr":
                         # (calls in flight walk the hops on their own spectra instead of the full SNR table: the hits' SNRs -- an
                         # intermediate, compared with the oracle at the same bar elsewhere -- agree to rounding, everything else bit for bit)
                         assert np.allclose(det_p[key], det[key], rtol=0.0, atol=parity.SNR_ATOL, equal_nan=True), key
                     else:
                         assert np.array_equal(np.asarray(det_p[key]), np.asarray(det[key]), equal_nan=True), key
                 fused, fell = cx.fused_tail_stats()
-                assert fused == (0 if stages == "1" else 8) and fell == 0
-                # depth back to 1 mid-way: joins, then behaves as ever
+                assert fused == 0 and fell == 0                    # (calls in flight never take the fused tail)
+                # depth back to 1 mid-way: joins, then behaves as ever (fused tail again)
                 cx.set_pipeline_depth(1)
                 g.calibrate_batch_dev(raw_t.data_ptr(), 64, n, setup["coef"], setup["ts"], FC, tabs[0].data_ptr(), ctx=cx)
                 cx.sync()
                 assert np.array_equal(tabs[0].cpu().numpy(), out["table"], equal_nan=True)
+                assert cx.fused_tail_stats()[0] == 1
+            finally:
                 cx.close()
-        finally:
-            os.environ.pop("GSMCAL_PIPE_STAGES", None)
 
 
 # ---- full BASELINE size: size-independent properties ---------------------------------------------------

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Round-6 record: the staged forms -- stages 2 / 3 -- exist only with profiles/experiments_r06/staged_pipeline_and_side_fused.patch
+# applied; the library in the tree has the side-by-side form, stages 1, and ignores GSMCAL_PIPE_STAGES.)
 # A/B of the pipelined headline loop in ONE session on one box: depth (calls in flight) x stages (1: whole calls side by side,
 # 2: front | tail, 3: front | fine search | fused tail).  Each run prints bench.py's line (headline + ms_per_step_depth1 / _llc_resident variants).
 #   tools/pipe_ab.sh <tag> [depth:stages ...]   -> gpurun_out/<tag>/d<depth>_s<stages>.json

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Round-6 record: stages 2 / 3 need profiles/experiments_r06/staged_pipeline_and_side_fused.patch; the library in the tree runs stages 1 only.)
 # rocprofv3 kernel timeline of the pipelined headline loop: who overlaps whom.
 #   tools/pipe_timeline.sh <tag> <depth> <stages>  -> gpurun_out/<tag>_timeline_d<depth>_s<stages>.csv (last 72 dispatches)
 set -u
