@@ -138,6 +138,11 @@ const char* gsmcal_version(void);
  * and are not in the library: profiles/experiments_r06/staged_pipeline_and_side_fused.patch, profiles/NOTES_r06.md.) */
 int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* ctx, int depth);
 int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* ctx);
+/* How many internal streams the context has SEEN running side by side (= hardware queues its calls in flight are spread over; the
+ * runtime hands out four): 0 before the first call in flight.  The context creates a dozen candidate streams at that call, keeps
+ * those that pass a 200-us pairwise probe and maps slot s to kept stream s mod that number -- which streams share a hardware queue
+ * depends on every stream the process created before (under PyTorch four streams created in a row landed on three queues). */
+int gsmcal_ctx_pipeline_queues(gsmcal_ctx* ctx);
 /* Diagnostics of the batch path's fused tail (one launch for everything behind the fine search's chunk sweep: its workgroups
  * exchange results inside the launch).  Several contexts may drive one GPU from several host threads; the library lets only one
  * such launch of the process be in flight per device and gives the later caller the four-launch tail (same results).

@@ -72,6 +72,7 @@ SIGNATURES = {
                                              C.c_void_p]),
     "gsmcal_ctx_set_pipeline_depth": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmcal_ctx_get_pipeline_depth": (C.c_int, [C.c_void_p]),
+    "gsmcal_ctx_pipeline_queues": (C.c_int, [C.c_void_p]),
     "gsmcal_fused_tail_reruns": (C.c_longlong, [C.c_void_p]),
     "gsmcal_fused_tail_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "gsmcal_comm_get_unique_id": (C.c_int, [C.c_void_p]),

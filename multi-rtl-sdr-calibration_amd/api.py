@@ -119,6 +119,10 @@ class Context:
     def pipeline_depth(self):
         return int(self.lib.gsmcal_ctx_get_pipeline_depth(self.h))
 
+    def pipeline_queues(self):
+        """gsmcal_ctx_pipeline_queues: internal streams seen running side by side (0 before the first call in flight)"""
+        return int(self.lib.gsmcal_ctx_pipeline_queues(self.h))
+
     def fused_tail_reruns(self):
         """how often gsmcal_sync / a host-buffer call re-ran calls with the four-launch tail after a fused tail timed out"""
         return int(self.lib.gsmcal_fused_tail_reruns(self.h))

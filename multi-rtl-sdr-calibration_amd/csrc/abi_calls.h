@@ -157,8 +157,8 @@ void gsmcal_ctx_destroy(gsmcal_ctx* c) {
             if (b->p) (void)hipFree(b->p);
         if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
         if (c->side_in[i]) (void)hipEventDestroy(c->side_in[i]);
-        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
     }
+    for (hipStream_t st : c->side_owned) (void)hipStreamDestroy(st);
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (hipEvent_t e : c->ag_chain)
         if (e) (void)hipEventDestroy(e);
@@ -233,6 +233,7 @@ int gsmcal_ctx_set_pipeline_depth(gsmcal_ctx* c, int depth) {
 }
 
 int gsmcal_ctx_get_pipeline_depth(gsmcal_ctx* c) { return c ? c->pipe_depth : GSMCAL_E_ARG; }
+int gsmcal_ctx_pipeline_queues(gsmcal_ctx* c) { return c ? c->n_side : GSMCAL_E_ARG; }
 
 const char* gsmcal_last_error(gsmcal_ctx* c) { return c ? c->err.c_str() : "null context"; }
 

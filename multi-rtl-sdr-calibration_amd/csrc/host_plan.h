@@ -116,7 +116,9 @@ struct gsmcal_ctx {
     static constexpr int PIPE_MAX_DEPTH = 8;
     int pipe_depth = 1;             // 1: a call is complete in stream order when it returns (the semantics of every earlier release)
     Lane pipe[PIPE_MAX_DEPTH];
-    hipStream_t side_stream[PIPE_MAX_DEPTH] = {};     // call i runs on side_stream[i mod depth]
+    hipStream_t side_stream[PIPE_MAX_DEPTH] = {};     // call i runs on side_stream[i mod depth]; entries repeat when fewer streams run side by side
+    std::vector<hipStream_t> side_owned;              // the distinct streams behind side_stream[] (pipe_pick_streams)
+    int n_side = 0;                                   // how many of them were seen running side by side (hardware queues they sit on)
     hipEvent_t side_in[PIPE_MAX_DEPTH] = {};          // the context's stream at the moment the slot's call was enqueued
     hipEvent_t pipe_done[PIPE_MAX_DEPTH] = {};        // end of the slot's call (plus a collective enqueued right behind it)
     bool pipe_pending[PIPE_MAX_DEPTH] = {};           // the slot's call has not been joined into the context's stream yet
@@ -1017,9 +1019,70 @@ int join_lanes(gsmcal_ctx* c, int nl) {
 }
 
 // ---- calls in flight: streams, events, joining ---------------------------------------------------------------------------
+// Two one-thread kernels that tell whether two streams sit on different hardware queues: the first spins (at most `ticks` of the
+// 100 MHz wall clock) until the second has raised the flag.  On one queue the second is dispatched behind the first and the spin
+// times out; on two queues it runs at once.
+__global__ void k_probe_spin(unsigned* flag, unsigned* seen, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    *seen = v;
+}
+__global__ void k_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+int streams_side_by_side(gsmcal_ctx* c, hipStream_t a, hipStream_t b, unsigned* d_words, bool* yes) {
+    HIPCHK(c, hipMemsetAsync(d_words, 0, 2 * sizeof(unsigned), a));
+    HIPCHK(c, hipStreamSynchronize(a));
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, a, d_words, d_words + 1, 20000ull);     // 200 us at most
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, d_words);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(a));
+    HIPCHK(c, hipStreamSynchronize(b));
+    unsigned seen = 0;
+    HIPCHK(c, hipMemcpy(&seen, d_words + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *yes = seen != 0;
+    return 0;
+}
+
+// The streams calls in flight run on.  The runtime hands its (four) hardware queues to new streams least-used first, and what
+// "least used" means depends on every stream the process has created so far: four streams created in a row can land on three
+// queues (measured under PyTorch: two of them on one queue, 0.158 instead of 0.127 ms per 64-stream call four deep).  So the
+// context creates a dozen candidates, keeps those it SEES running side by side with all it has kept so far (a 200-us probe per
+// pair, once per context) and gives the rest back; slot s runs on kept stream s mod n_side.
+int pipe_pick_streams(gsmcal_ctx* c) {
+    constexpr int NC = 12;
+    hipStream_t cand[NC] = {};
+    for (int i = 0; i < NC; ++i) HIPCHK(c, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));   // (default priority: a higher one for some slots measured no better, NOTES_r06)
+    unsigned* d_words = nullptr;
+    int rc = hipMalloc((void**)&d_words, 2 * sizeof(unsigned)) == hipSuccess ? 0 : GSMCAL_E_HIP;
+    std::vector<int> kept;
+    for (int i = 0; rc >= 0 && i < NC && (int)kept.size() < gsmcal_ctx::PIPE_MAX_DEPTH; ++i) {
+        bool ok = true;
+        for (int k : kept) {
+            rc = streams_side_by_side(c, cand[k], cand[i], d_words, &ok);
+            if (rc < 0 || !ok) break;
+        }
+        if (rc >= 0 && ok) kept.push_back(i);
+    }
+    if (d_words) (void)hipFree(d_words);
+    if (rc < 0 || kept.empty()) {                          // (the probe itself failed: the first streams, as created)
+        (void)hipGetLastError();
+        kept.clear();
+        for (int i = 0; i < 4; ++i) kept.push_back(i);
+    }
+    for (int i = 0; i < NC; ++i) {
+        bool keep = false;
+        for (int k : kept) keep = keep || k == i;
+        if (keep) c->side_owned.push_back(cand[i]); else (void)hipStreamDestroy(cand[i]);
+    }
+    c->n_side = (int)c->side_owned.size();
+    for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) c->side_stream[s] = c->side_owned[s % c->n_side];
+    return 0;
+}
+
 int pipe_prepare(gsmcal_ctx* c) {
+    if (c->n_side == 0) RET_IF(pipe_pick_streams(c));
     for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) {
-        if (!c->side_stream[s]) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[s], hipStreamNonBlocking));   // (default priority: a higher one for some slots measured no better, NOTES_r06)
         if (!c->side_in[s] && hipEventCreateWithFlags(&c->side_in[s], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
             (void)hipGetLastError();
             HIPCHK(c, hipEventCreateWithFlags(&c->side_in[s], hipEventDisableTiming));
@@ -1054,8 +1117,7 @@ int pipe_drain(gsmcal_ctx* c) {
     bool any = false;
     for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s) any = any || c->pipe_pending[s];
     if (any)
-        for (int s = 0; s < gsmcal_ctx::PIPE_MAX_DEPTH; ++s)
-            if (c->side_stream[s]) HIPCHK(c, hipStreamSynchronize(c->side_stream[s]));
+        for (hipStream_t st : c->side_owned) HIPCHK(c, hipStreamSynchronize(st));
     return pipe_join(c);
 }
 

@@ -751,6 +751,7 @@ def test_unlike_calls_in_flight(g, setup):
                     outs.append((tab, pos, rl))
                 keep.append(r_t)
             assert cx.pipeline_depth() == 3
+            assert 1 <= cx.pipeline_queues() <= 8               # (four on the pool's boxes: the runtime's hardware queues)
             cx.sync()
             for k, ((kind, rows, coef, fc, _), ref, out) in enumerate(zip(plan, refs, outs)):
                 if kind == "scan":
