@@ -1052,6 +1052,9 @@ int streams_side_by_side(gsmcal_ctx* c, hipStream_t a, hipStream_t b, unsigned* 
 int pipe_pick_streams(gsmcal_ctx* c) {
     constexpr int NC = 12;
     hipStream_t cand[NC] = {};
+    // (work still queued on the context's stream would hold up a probe kernel that shares its hardware queue and make two good
+    // streams look like one: the first call in flight of a context waits for it -- once)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < NC; ++i) HIPCHK(c, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));   // (default priority: a higher one for some slots measured no better, NOTES_r06)
     unsigned* d_words = nullptr;
     int rc = hipMalloc((void**)&d_words, 2 * sizeof(unsigned)) == hipSuccess ? 0 : GSMCAL_E_HIP;
